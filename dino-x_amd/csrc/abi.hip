@@ -1,0 +1,59 @@
+// abi.hip -- error plumbing and library-level entry points of libdinox_hip.so.
+#include <cstdarg>
+#include <cstring>
+
+#include "common.h"
+
+namespace dinox {
+
+static thread_local char g_err[512] = {0};
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}
+
+}  // namespace dinox
+
+extern "C" int dinox_version(void) { return DINOX_ABI_VERSION; }
+
+extern "C" const char* dinox_last_error(void) { return dinox::g_err; }
+
+extern "C" int dinox_device_ok(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
+    dinox::set_error("no HIP device visible");
+    return 0;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    dinox::set_error("hipGetDeviceProperties failed");
+    return 0;
+  }
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    dinox::set_error("device 0 is %s, this library is built for gfx950 only", prop.gcnArchName);
+    return 0;
+  }
+  return 1;
+}

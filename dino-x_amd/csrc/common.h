@@ -1,0 +1,95 @@
+// common.h -- shared device/host helpers for libdinox_hip (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cstdio>
+#include <string>
+
+#include "../../include/dinox.h"
+
+namespace dinox {
+
+// ---------------------------------------------------------------- host: error plumbing
+void set_error(const char* fmt, ...);
+int fail(int code, const char* fmt, ...);
+int check_launch(const char* what);  // hipGetLastError -> 0 or positive hipError_t
+
+#define DX_REQUIRE(cond, code, ...)                  \
+  do {                                               \
+    if (!(cond)) return ::dinox::fail((code), __VA_ARGS__); \
+  } while (0)
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------- device: types
+typedef uint16_t bf16_t;  // raw bf16 bits
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+// Plain cast: hipcc emits v_cvt_pk_bf16_f32 (RNE, keeps NaN a NaN) -- MI355X_MICROARCH correctness table.
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(bf16_t, b);
+}
+
+template <int DT>
+struct elem;
+template <>
+struct elem<DINOX_F32> {
+  using type = float;
+  static __device__ __forceinline__ float ld(const void* p, int64_t i) { return ((const float*)p)[i]; }
+  static __device__ __forceinline__ void st(void* p, int64_t i, float v) { ((float*)p)[i] = v; }
+};
+template <>
+struct elem<DINOX_BF16> {
+  using type = bf16_t;
+  static __device__ __forceinline__ float ld(const void* p, int64_t i) { return bf16_to_f32(((const bf16_t*)p)[i]); }
+  static __device__ __forceinline__ void st(void* p, int64_t i, float v) { ((bf16_t*)p)[i] = f32_to_bf16(v); }
+};
+
+// ---------------------------------------------------------------- device: math
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * __expf(-0.5f * x * x) * 0.39894228040143268f;
+}
+
+// ---------------------------------------------------------------- device: reductions (wave64)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// Block-wide sum; every thread gets the result. `red` is >= 16 floats of LDS. blockDim.x multiple of 64.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < nw; ++i) t += red[i];
+  return t;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+  v = wave_max(v);
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float t = red[0];
+  for (int i = 1; i < nw; ++i) t = fmaxf(t, red[i]);
+  return t;
+}
+
+}  // namespace dinox

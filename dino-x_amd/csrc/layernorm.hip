@@ -1,0 +1,311 @@
+// layernorm.hip -- LayerNorm forward/backward over the fp32 residual stream.
+// Replaces nn.LayerNorm(D) (reference zoo/arch.py:89,91,126,187).  HBM-bound: one wave per row, the
+// row is read once into registers (float4 per lane), statistics by wave shuffles, no LDS on the
+// forward path.  Algorithmic bytes per row: fwd 4D read + (4|2)D write; bwd (4|2)D + 4D read, 4D
+// (+4D when accumulating, +2D for the bf16 copy) written.
+#include "common.h"
+
+namespace dinox {
+
+constexpr int LN_THREADS = 256;   // 4 waves = 4 rows in flight per block
+constexpr int LN_MAXV = 8;        // float4 per lane kept in registers -> dim <= 2048 on the fast path
+constexpr int LN_MAX_PARTS = 1024;
+
+template <int OUT_DT, int NV>
+__global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ b, void* __restrict__ y,
+                                                            float* __restrict__ mean, float* __restrict__ rstd,
+                                                            int64_t rows, int dim, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * (LN_THREADS / 64) + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (LN_THREADS / 64);
+  const int nvec = dim >> 2;
+  const float inv = 1.0f / (float)dim;
+  for (int64_t r = wave; r < rows; r += nwaves) {
+    const float4* xr = reinterpret_cast<const float4*>(x + r * dim);
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int c = lane + 64 * j;
+      v[j] = (c < nvec) ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+      s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    }
+    const float mu = wave_sum(s) * inv;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int c = lane + 64 * j;
+      if (c < nvec) {
+        const float a = v[j].x - mu, bb = v[j].y - mu, cc = v[j].z - mu, d = v[j].w - mu;
+        q += (a * a + bb * bb) + (cc * cc + d * d);
+      }
+    }
+    const float rs = rsqrtf(wave_sum(q) * inv + eps);
+    if (lane == 0) {
+      mean[r] = mu;
+      rstd[r] = rs;
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int c = lane + 64 * j;
+      if (c < nvec) {
+        const float4 ww = reinterpret_cast<const float4*>(w)[c];
+        const float4 bb = reinterpret_cast<const float4*>(b)[c];
+        float4 o;
+        o.x = (v[j].x - mu) * rs * ww.x + bb.x;
+        o.y = (v[j].y - mu) * rs * ww.y + bb.y;
+        o.z = (v[j].z - mu) * rs * ww.z + bb.z;
+        o.w = (v[j].w - mu) * rs * ww.w + bb.w;
+        if (OUT_DT == DINOX_F32) {
+          reinterpret_cast<float4*>((float*)y + r * dim)[c] = o;
+        } else {
+          ushort4 p;
+          p.x = f32_to_bf16(o.x);
+          p.y = f32_to_bf16(o.y);
+          p.z = f32_to_bf16(o.z);
+          p.w = f32_to_bf16(o.w);
+          reinterpret_cast<ushort4*>((bf16_t*)y + r * dim)[c] = p;
+        }
+      }
+    }
+  }
+}
+
+// Generic (any dim) fallback: one wave per row, three cached passes.
+template <int OUT_DT>
+__global__ __launch_bounds__(LN_THREADS) void ln_fwd_generic(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ b, void* __restrict__ y,
+                                                             float* __restrict__ mean, float* __restrict__ rstd,
+                                                             int64_t rows, int dim, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * (LN_THREADS / 64) + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (LN_THREADS / 64);
+  const float inv = 1.0f / (float)dim;
+  for (int64_t r = wave; r < rows; r += nwaves) {
+    const float* xr = x + r * dim;
+    float s = 0.f;
+    for (int c = lane; c < dim; c += 64) s += xr[c];
+    const float mu = wave_sum(s) * inv;
+    float q = 0.f;
+    for (int c = lane; c < dim; c += 64) {
+      const float d = xr[c] - mu;
+      q += d * d;
+    }
+    const float rs = rsqrtf(wave_sum(q) * inv + eps);
+    if (lane == 0) {
+      mean[r] = mu;
+      rstd[r] = rs;
+    }
+    for (int c = lane; c < dim; c += 64) elem<OUT_DT>::st(y, r * dim + c, (xr[c] - mu) * rs * w[c] + b[c]);
+  }
+}
+
+// Backward, stage 1.  Each lane owns fixed columns, so dw/db partial sums stay in registers across
+// the rows its wave visits; the block's 4 waves are combined through LDS and one partial row per
+// block is written to ws[part][2][dim].  Stage 2 sums the parts.
+template <int DY_DT, int NV>
+__global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const void* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ w, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, float* __restrict__ dx,
+                                                            void* __restrict__ dx_lowp, float* __restrict__ ws,
+                                                            int64_t rows, int dim, int accumulate) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t wave = (int64_t)blockIdx.x * (LN_THREADS / 64) + wv;
+  const int64_t nwaves = (int64_t)gridDim.x * (LN_THREADS / 64);
+  const int nvec = dim >> 2;
+  const float inv = 1.0f / (float)dim;
+  float4 aw[NV], ab[NV], wreg[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    aw[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    ab[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int c = lane + 64 * j;
+    wreg[j] = (c < nvec) ? reinterpret_cast<const float4*>(w)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int64_t r = wave; r < rows; r += nwaves) {
+    const float mu = mean[r], rs = rstd[r];
+    float4 xh[NV], g[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int c = lane + 64 * j;
+      float4 d = make_float4(0.f, 0.f, 0.f, 0.f), xv = make_float4(mu, mu, mu, mu);
+      if (c < nvec) {
+        xv = reinterpret_cast<const float4*>(x + r * dim)[c];
+        if (DY_DT == DINOX_F32) {
+          d = reinterpret_cast<const float4*>((const float*)dy + r * dim)[c];
+        } else {
+          const ushort4 p = reinterpret_cast<const ushort4*>((const bf16_t*)dy + r * dim)[c];
+          d = make_float4(bf16_to_f32(p.x), bf16_to_f32(p.y), bf16_to_f32(p.z), bf16_to_f32(p.w));
+        }
+      }
+      xh[j] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+      g[j] = make_float4(d.x * wreg[j].x, d.y * wreg[j].y, d.z * wreg[j].z, d.w * wreg[j].w);
+      aw[j].x += d.x * xh[j].x; aw[j].y += d.y * xh[j].y; aw[j].z += d.z * xh[j].z; aw[j].w += d.w * xh[j].w;
+      ab[j].x += d.x; ab[j].y += d.y; ab[j].z += d.z; ab[j].w += d.w;
+      s1 += (g[j].x + g[j].y) + (g[j].z + g[j].w);
+      s2 += (g[j].x * xh[j].x + g[j].y * xh[j].y) + (g[j].z * xh[j].z + g[j].w * xh[j].w);
+    }
+    const float m1 = wave_sum(s1) * inv, m2 = wave_sum(s2) * inv;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int c = lane + 64 * j;
+      if (c < nvec) {
+        float4 o;
+        o.x = rs * (g[j].x - m1 - xh[j].x * m2);
+        o.y = rs * (g[j].y - m1 - xh[j].y * m2);
+        o.z = rs * (g[j].z - m1 - xh[j].z * m2);
+        o.w = rs * (g[j].w - m1 - xh[j].w * m2);
+        float4* dst = reinterpret_cast<float4*>(dx + r * dim) + c;
+        if (accumulate) {
+          const float4 p = *dst;
+          o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+        }
+        *dst = o;
+        if (dx_lowp) {
+          ushort4 p;
+          p.x = f32_to_bf16(o.x); p.y = f32_to_bf16(o.y); p.z = f32_to_bf16(o.z); p.w = f32_to_bf16(o.w);
+          reinterpret_cast<ushort4*>((bf16_t*)dx_lowp + r * dim)[c] = p;
+        }
+      }
+    }
+  }
+  // combine the 4 waves: lds[wv][2][dim]
+  float* mine = lds + (size_t)wv * 2 * dim;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int c = lane + 64 * j;
+    if (c < nvec) {
+      reinterpret_cast<float4*>(mine)[c] = aw[j];
+      reinterpret_cast<float4*>(mine + dim)[c] = ab[j];
+    }
+  }
+  __syncthreads();
+  float* out = ws + (size_t)blockIdx.x * 2 * dim;
+  for (int c = threadIdx.x; c < 2 * dim; c += LN_THREADS)
+    out[c] = (lds[c] + lds[2 * dim + c]) + (lds[4 * dim + c] + lds[6 * dim + c]);
+}
+
+template <int DY_DT>
+__global__ __launch_bounds__(LN_THREADS) void ln_bwd_generic(const void* __restrict__ dy, const float* __restrict__ x,
+                                                             const float* __restrict__ w, const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd, float* __restrict__ dx,
+                                                             void* __restrict__ dx_lowp, float* __restrict__ ws,
+                                                             int64_t rows, int dim, int accumulate) {
+  // Generic fallback: one wave per row for dx; dw/db partials via LDS atomics per block.
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  for (int c = threadIdx.x; c < 2 * dim; c += LN_THREADS) lds[c] = 0.f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * (LN_THREADS / 64) + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (LN_THREADS / 64);
+  const float inv = 1.0f / (float)dim;
+  for (int64_t r = wave; r < rows; r += nwaves) {
+    const float mu = mean[r], rs = rstd[r];
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = lane; c < dim; c += 64) {
+      const float d = elem<DY_DT>::ld(dy, r * dim + c), xh = (x[r * dim + c] - mu) * rs, g = d * w[c];
+      s1 += g;
+      s2 += g * xh;
+      atomicAdd(&lds[c], d * xh);
+      atomicAdd(&lds[dim + c], d);
+    }
+    const float m1 = wave_sum(s1) * inv, m2 = wave_sum(s2) * inv;
+    for (int c = lane; c < dim; c += 64) {
+      const float d = elem<DY_DT>::ld(dy, r * dim + c), xh = (x[r * dim + c] - mu) * rs;
+      float o = rs * (d * w[c] - m1 - xh * m2);
+      if (accumulate) o += dx[r * dim + c];
+      dx[r * dim + c] = o;
+      if (dx_lowp) ((bf16_t*)dx_lowp)[r * dim + c] = f32_to_bf16(o);
+    }
+  }
+  __syncthreads();
+  float* out = ws + (size_t)blockIdx.x * 2 * dim;
+  for (int c = threadIdx.x; c < 2 * dim; c += LN_THREADS) out[c] = lds[c];
+}
+
+__global__ void ln_bwd_reduce(const float* __restrict__ ws, float* __restrict__ dw, float* __restrict__ db, int parts,
+                              int dim) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= 2 * dim) return;
+  float s = 0.f;
+  for (int p = 0; p < parts; ++p) s += ws[(size_t)p * 2 * dim + c];
+  if (c < dim) dw[c] = s; else db[c - dim] = s;
+}
+
+static int ln_parts(int64_t rows) {
+  int64_t p = ceil_div(rows, LN_THREADS / 64);
+  return (int)(p < LN_MAX_PARTS ? p : LN_MAX_PARTS);
+}
+
+}  // namespace dinox
+
+using namespace dinox;
+
+extern "C" int dinox_layernorm_fwd(const float* x, const float* w, const float* b, void* y, float* mean, float* rstd,
+                                   int64_t rows, int dim, float eps, int out_dtype, void* stream) {
+  DX_REQUIRE(x && w && b && y && mean && rstd, DINOX_EINVAL, "layernorm_fwd: null pointer");
+  DX_REQUIRE(rows > 0 && dim > 0, DINOX_EINVAL, "layernorm_fwd: rows=%lld dim=%d", (long long)rows, dim);
+  DX_REQUIRE(out_dtype == DINOX_F32 || out_dtype == DINOX_BF16, DINOX_EINVAL, "layernorm_fwd: dtype %d", out_dtype);
+  int64_t blocks = ceil_div(rows, LN_THREADS / 64);
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipStream_t st = as_stream(stream);
+  const bool fast = (dim % 4 == 0) && dim <= 256 * LN_MAXV;
+#define LN_FWD(DT, NV) hipLaunchKernelGGL((ln_fwd_kernel<DT, NV>), dim3((unsigned)blocks), dim3(LN_THREADS), 0, st, x, w, b, y, mean, rstd, rows, dim, eps)
+  if (fast) {
+    const int nv = (int)ceil_div(dim / 4, 64);
+    if (out_dtype == DINOX_F32) {
+      if (nv <= 1) LN_FWD(DINOX_F32, 1); else if (nv <= 2) LN_FWD(DINOX_F32, 2); else if (nv <= 4) LN_FWD(DINOX_F32, 4); else LN_FWD(DINOX_F32, 8);
+    } else {
+      if (nv <= 1) LN_FWD(DINOX_BF16, 1); else if (nv <= 2) LN_FWD(DINOX_BF16, 2); else if (nv <= 4) LN_FWD(DINOX_BF16, 4); else LN_FWD(DINOX_BF16, 8);
+    }
+  } else {
+    if (out_dtype == DINOX_F32)
+      hipLaunchKernelGGL((ln_fwd_generic<DINOX_F32>), dim3((unsigned)blocks), dim3(LN_THREADS), 0, st, x, w, b, y, mean, rstd, rows, dim, eps);
+    else
+      hipLaunchKernelGGL((ln_fwd_generic<DINOX_BF16>), dim3((unsigned)blocks), dim3(LN_THREADS), 0, st, x, w, b, y, mean, rstd, rows, dim, eps);
+  }
+#undef LN_FWD
+  return check_launch("layernorm_fwd");
+}
+
+extern "C" int64_t dinox_layernorm_bwd_ws_bytes(int64_t rows, int dim) {
+  if (rows <= 0 || dim <= 0) return 0;
+  return (int64_t)ln_parts(rows) * 2 * dim * (int64_t)sizeof(float);
+}
+
+extern "C" int dinox_layernorm_bwd(const void* dy, const float* x, const float* w, const float* mean, const float* rstd,
+                                   float* dx, void* dx_lowp, float* dw, float* db, void* ws, int64_t rows, int dim,
+                                   int dy_dtype, int accumulate_dx, void* stream) {
+  DX_REQUIRE(dy && x && w && mean && rstd && dx && dw && db && ws, DINOX_EINVAL, "layernorm_bwd: null pointer");
+  DX_REQUIRE(rows > 0 && dim > 0, DINOX_EINVAL, "layernorm_bwd: rows=%lld dim=%d", (long long)rows, dim);
+  DX_REQUIRE(dy_dtype == DINOX_F32 || dy_dtype == DINOX_BF16, DINOX_EINVAL, "layernorm_bwd: dtype %d", dy_dtype);
+  const int parts = ln_parts(rows);
+  hipStream_t st = as_stream(stream);
+  const size_t lds = (size_t)(LN_THREADS / 64) * 2 * dim * sizeof(float);
+  const bool fast = (dim % 4 == 0) && dim <= 256 * LN_MAXV && lds <= 64 * 1024;
+  float* wsf = (float*)ws;
+#define LN_BWD(DT, NV) hipLaunchKernelGGL((ln_bwd_kernel<DT, NV>), dim3(parts), dim3(LN_THREADS), lds, st, dy, x, w, mean, rstd, dx, dx_lowp, wsf, rows, dim, accumulate_dx)
+  if (fast) {
+    const int nv = (int)ceil_div(dim / 4, 64);
+    if (dy_dtype == DINOX_F32) {
+      if (nv <= 1) LN_BWD(DINOX_F32, 1); else if (nv <= 2) LN_BWD(DINOX_F32, 2); else if (nv <= 4) LN_BWD(DINOX_F32, 4); else LN_BWD(DINOX_F32, 8);
+    } else {
+      if (nv <= 1) LN_BWD(DINOX_BF16, 1); else if (nv <= 2) LN_BWD(DINOX_BF16, 2); else if (nv <= 4) LN_BWD(DINOX_BF16, 4); else LN_BWD(DINOX_BF16, 8);
+    }
+  } else {
+    const size_t l2 = (size_t)2 * dim * sizeof(float);
+    DX_REQUIRE(l2 <= 64 * 1024, DINOX_EUNSUPPORTED, "layernorm_bwd: dim %d too large", dim);
+    if (dy_dtype == DINOX_F32)
+      hipLaunchKernelGGL((ln_bwd_generic<DINOX_F32>), dim3(parts), dim3(LN_THREADS), l2, st, dy, x, w, mean, rstd, dx, dx_lowp, wsf, rows, dim, accumulate_dx);
+    else
+      hipLaunchKernelGGL((ln_bwd_generic<DINOX_BF16>), dim3(parts), dim3(LN_THREADS), l2, st, dy, x, w, mean, rstd, dx, dx_lowp, wsf, rows, dim, accumulate_dx);
+  }
+#undef LN_BWD
+  int rc = check_launch("layernorm_bwd");
+  if (rc) return rc;
+  hipLaunchKernelGGL(ln_bwd_reduce, dim3((unsigned)ceil_div(2 * dim, 256)), dim3(256), 0, st, wsf, dw, db, parts, dim);
+  return check_launch("layernorm_bwd_reduce");
+}

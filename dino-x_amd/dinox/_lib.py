@@ -1,0 +1,99 @@
+"""ctypes binding of libdinox_hip.so (the C ABI declared in include/dinox.h).
+
+The library is the product's only compute path: if it is missing or cannot be loaded this module
+raises -- there is no eager/PyTorch/CPU fallback anywhere in the package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdinox_hip.so")
+
+F32, BF16 = 0, 1
+EPI_BIAS, EPI_GELU, EPI_DGELU, EPI_RESIDUAL, EPI_ACCUM = 1, 2, 4, 8, 16
+
+vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+
+class GemmArgs(C.Structure):
+    """struct dinox_gemm_args (include/dinox.h)."""
+    _fields_ = [
+        ("A", vp), ("B", vp), ("C", vp),
+        ("M", i64), ("N", i64), ("K", i64),
+        ("lda", i64), ("ldb", i64), ("ldc", i64),
+        ("batch", i64), ("strideA", i64), ("strideB", i64), ("strideC", i64),
+        ("transA", i32), ("transB", i32), ("in_dtype", i32), ("out_dtype", i32), ("epilogue", i32),
+        ("alpha", f32),
+        ("bias", vp), ("residual", vp), ("ldr", i64), ("aux", vp), ("ldaux", i64),
+    ]
+
+
+# name -> (restype, argtypes); order and types mirror include/dinox.h exactly.
+SIGNATURES = {
+    "dinox_version": (i32, []),
+    "dinox_last_error": (C.c_char_p, []),
+    "dinox_device_ok": (i32, []),
+    "dinox_gemm": (i32, [C.POINTER(GemmArgs), vp]),
+    "dinox_colsum": (i32, [vp, vp, i64, i64, i64, i32, i32, vp]),
+    "dinox_layernorm_fwd": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, f32, i32, vp]),
+    "dinox_layernorm_bwd_ws_bytes": (i64, [i64, i32]),
+    "dinox_layernorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]),
+    "dinox_attention_fwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "dinox_attention_bwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "dinox_patch_unfold": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "dinox_tokens_fwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "dinox_tokens_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "dinox_scale_embed_fwd": (i32, [vp] * 12 + [i32, i32, i32, f32, vp]),
+    "dinox_scale_embed_bwd_ws_bytes": (i64, [i32, i32, i32]),
+    "dinox_scale_embed_bwd": (i32, [vp] * 17 + [i32, i32, i32, vp]),
+    "dinox_dino_ce": (i32, [vp, vp, vp, f32, f32, f32, vp, vp, vp, i32, i32, vp]),
+    "dinox_colmean": (i32, [vp, vp, i32, i32, vp]),
+    "dinox_center_ema": (i32, [vp, vp, f32, i32, vp]),
+    "dinox_gram_normalize": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "dinox_sqsum": (i32, [vp, i64, f32, vp, vp, vp]),
+    "dinox_gram_normalize_bwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "dinox_adamw_ema": (i32, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, f32, vp, vp, vp]),
+    "dinox_sumsq": (i32, [vp, i64, vp, vp, vp]),
+    "dinox_cast_bf16": (i32, [vp, vp, i64, vp]),
+    "dinox_cast_transpose_bf16": (i32, [vp, vp, i32, i32, vp]),
+    "dinox_gelu_fwd": (i32, [vp, vp, i64, vp]),
+    "dinox_gelu_bwd": (i32, [vp, vp, vp, i64, vp]),
+}
+
+
+class DinoxLibraryError(ImportError):
+    pass
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise DinoxLibraryError(
+            f"{LIB_PATH} not found: the HIP kernel library is the only compute path of this package "
+            "(no CPU/eager fallback). Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C dino-x_amd/csrc`.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # missing libamdhip64 etc.
+        raise DinoxLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise DinoxLibraryError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def last_error() -> str:
+    return lib.dinox_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (code {rc}): {last_error()}")

@@ -1,0 +1,140 @@
+"""Data-parallel plumbing: one process per GPU, torch.distributed over RCCL (backend "nccl" on ROCm).
+
+The reference is single-process; data parallelism is this engine's addition.
+The global batch is partitioned by source sample (both views of a sample stay on one rank, so the
+cross-view split of DINOLoss stays local).  Per optimiser step there are exactly two exchanges:
+
+1. sum all-reduce of the student gradient arena, in buckets that are contiguous slices of ONE flat fp32
+   buffer.  Buckets are cut in *reverse* parameter order (the order backward produces gradients) and each
+   is launched asynchronously from a post-accumulate-grad hook as soon as its last gradient lands, so
+   the collective overlaps the rest of backward on RCCL's own stream.  xGMI is point-to-point
+   (7 links x ~153 GB/s per GPU) and ring collectives are per-link bound, so buckets are few and large
+   (default 32 MiB: ViT-S = 4 buckets, ViT-L = ~38) rather than NVSwitch-style small ones.
+2. sum all-reduce of the 8192-float teacher batch mean before the centre EMA, so that every rank holds
+   the centre of the *global* batch (scripts/phase5_big_run.py:689-690).
+
+The 1/world scaling of (1) is folded into the fused AdamW kernel (``grad_scale``); no extra pass.
+Everything here is device-agnostic: the same code runs under ``gloo`` on CPU tensors in the tests.
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def env_rank_world() -> Tuple[int, int, int]:
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init_process_group(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    """Initialise torch.distributed from the torchrun environment (no-op for world size 1)."""
+    rank, world, local = env_rank_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_range(n_samples: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous, equal sample shard of a global batch (global batch must divide evenly)."""
+    if n_samples % world:
+        raise ValueError(f"global batch {n_samples} is not divisible by world size {world}")
+    per = n_samples // world
+    return rank * per, (rank + 1) * per
+
+
+@dataclass
+class _Bucket:
+    lo: int            # element range [lo, hi) of the flat gradient arena
+    hi: int
+    pending: int       # parameters whose gradient has not landed yet (this step)
+    n_params: int
+    work: Optional[object] = None
+
+
+class GradBucketer:
+    """Bucketed asynchronous all-reduce over a flat gradient arena.
+
+    ``params`` are the parameters in arena order; ``offsets[i]`` is the element offset of params[i] in
+    ``flat_grad``.  Call ``arm()`` before backward, ``finish()`` after it (waits for every bucket)."""
+
+    def __init__(self, params: Sequence[torch.nn.Parameter], offsets: Sequence[int], flat_grad: torch.Tensor,
+                 bucket_bytes: int = 32 << 20, group=None) -> None:
+        self.flat = flat_grad
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.buckets: List[_Bucket] = []
+        self.bucket_of: Dict[int, int] = {}
+        cap = max(1, bucket_bytes // flat_grad.element_size())
+        # walk parameters from last to first; a bucket is a contiguous slice [lo, hi)
+        hi = None
+        lo = None
+        members: List[int] = []
+        for i in range(len(params) - 1, -1, -1):
+            p_lo, p_hi = offsets[i], offsets[i] + params[i].numel()
+            if hi is None:
+                hi, lo, members = p_hi, p_lo, [i]
+            else:
+                lo = p_lo
+                members.append(i)
+            if hi - lo >= cap or i == 0:
+                b = len(self.buckets)
+                self.buckets.append(_Bucket(lo=lo, hi=hi, pending=len(members), n_params=len(members)))
+                for j in members:
+                    self.bucket_of[j] = b
+                hi = None
+        self._hooks = []
+        if self.world > 1:
+            for i, p in enumerate(params):
+                if p.requires_grad:
+                    self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+
+    def _make_hook(self, i: int):
+        def hook(_param):
+            self.grad_ready(i)
+        return hook
+
+    def arm(self) -> None:
+        for b in self.buckets:
+            b.pending = b.n_params
+            b.work = None
+
+    def grad_ready(self, i: int) -> None:
+        b = self.buckets[self.bucket_of[i]]
+        b.pending -= 1
+        if b.pending == 0 and self.world > 1:
+            b.work = dist.all_reduce(self.flat[b.lo:b.hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def finish(self) -> None:
+        """Launch any bucket that never filled (parameters without gradient) and wait for all."""
+        if self.world <= 1:
+            return
+        for b in self.buckets:
+            if b.work is None:
+                b.work = dist.all_reduce(self.flat[b.lo:b.hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        for b in self.buckets:
+            b.work.wait()
+            b.work = None
+
+    def remove(self) -> None:
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+
+def all_reduce_mean_(t: torch.Tensor, group=None) -> torch.Tensor:
+    """In-place mean over ranks (no-op for world size 1)."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        t.div_(dist.get_world_size(group))
+    return t

@@ -1,0 +1,144 @@
+"""Training engine: one DINO-X optimiser step on the HIP kernels, optionally data-parallel.
+
+Follows the order of the reference loop (scripts/phase5_big_run.py:1692-1802) for
+``--loss-type dino`` with ``accumulation_steps == 1``:
+
+    lr = get_lr(step)                                              :1692-1700
+    student fwd, teacher fwd (no grad), heads on CLS                :1741-1747
+    DINO loss with the PRE-update centre, then centre EMA           :1749-1755 -> :692-720
+    + gram_weight * Gram anchoring loss                             :1758-1761
+    backward                                                        :1772
+    global grad-norm, AdamW (wd on every parameter), EMA teacher    :1781-1802
+
+What is different from the reference, by design:
+  * parameters, gradients, Adam moments and teacher weights live in flat fp32 arenas, so the grad-norm,
+    AdamW and EMA are ONE kernel pass (dinox_adamw_ema) instead of 161 x (.item() + 2 EMA launches);
+  * no host synchronisation inside a step: loss and grad-norm stay on the device until asked for;
+  * data parallel: bucketed RCCL all-reduce of the gradient arena overlapped with backward, centre
+    batch-mean all-reduced, 1/world folded into the AdamW kernel (dinox/dp.py).
+Documented deviation: the reference's AdamW skips parameters whose ``.grad`` is None (only possible for
+``scale_embed.*`` when a scale-aware model is stepped with ``spacing=None``); the arena pass applies
+weight decay to them.  The reference loop always passes spacing for scale-aware models (:1713).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+from .dp import GradBucketer, all_reduce_mean_
+from .schedule import get_lr
+
+
+@dataclass
+class StepHyperParams:
+    """Defaults are the reference CLI defaults (scripts/phase5_big_run.py:1264-1285)."""
+    lr: float = 1e-4
+    min_lr: float = 1e-6
+    warmup_steps: int = 2500
+    max_steps: Optional[int] = None
+    weight_decay: float = 0.04
+    ema: float = 0.996
+    teacher_temp: float = 0.04
+    student_temp: float = 0.1
+    center_momentum: float = 0.9
+    gram_weight: float = 1.0
+    beta1: float = 0.9
+    beta2: float = 0.999
+    adam_eps: float = 1e-8
+
+
+def flatten_parameters(module: torch.nn.Module, align: int = 4) -> Tuple[torch.Tensor, List[torch.nn.Parameter], List[int]]:
+    """Move every parameter of ``module`` into one flat fp32 arena (each at a 16-byte aligned offset)
+    and re-point ``p.data`` at its slice.  Returns (arena, params in arena order, element offsets)."""
+    params = list(module.parameters())
+    if not params:
+        raise ValueError("module has no parameters")
+    dev = params[0].device
+    offsets, total = [], 0
+    for p in params:
+        if p.dtype != torch.float32:
+            raise TypeError("master parameters must be fp32")
+        offsets.append(total)
+        total += (p.numel() + align - 1) // align * align
+    flat = torch.zeros(total, dtype=torch.float32, device=dev)
+    for p, off in zip(params, offsets):
+        flat[off:off + p.numel()].copy_(p.data.reshape(-1))
+        p.data = flat[off:off + p.numel()].view(p.shape)
+    return flat, params, offsets
+
+
+class TrainEngine:
+    """Owns student/teacher arenas, the DINO centre and the optimiser state; ``step()`` runs one update."""
+
+    def __init__(self, student: torch.nn.Module, teacher: torch.nn.Module, out_dim: int, hp: StepHyperParams,
+                 amp_dtype: Optional[torch.dtype] = None, process_group=None, bucket_bytes: int = 32 << 20) -> None:
+        self.student, self.teacher, self.hp = student, teacher, hp
+        self.compute_dtype = amp_dtype or torch.float32
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        for p in teacher.parameters():
+            p.requires_grad_(False)
+        self.flat_p, self.params, self.offsets = flatten_parameters(student)
+        self.flat_t, t_params, t_off = flatten_parameters(teacher)
+        if t_off != self.offsets or self.flat_t.numel() != self.flat_p.numel():
+            raise ValueError("student and teacher must have identical parameter layouts")
+        if self.world > 1:                                   # identical start on every rank
+            dist.broadcast(self.flat_p, src=0, group=process_group)
+            dist.broadcast(self.flat_t, src=0, group=process_group)
+        self.flat_g = torch.zeros_like(self.flat_p)
+        self.adam_m = torch.zeros_like(self.flat_p)
+        self.adam_v = torch.zeros_like(self.flat_p)
+        for p, off in zip(self.params, self.offsets):
+            p.grad = self.flat_g[off:off + p.numel()].view(p.shape)
+        dev = self.flat_p.device
+        self.center = torch.zeros(1, out_dim, dtype=torch.float32, device=dev)
+        self.bucketer = GradBucketer(self.params, self.offsets, self.flat_g, bucket_bytes=bucket_bytes, group=process_group)
+        self.step_count = 0          # micro-batches seen (drives the LR schedule, like the reference)
+        self.opt_steps = 0           # optimiser steps taken (AdamW bias correction)
+        self.last = {}
+
+    # -- one optimiser step ---------------------------------------------------------------------
+    def step(self, batch: torch.Tensor, spacing2b: Optional[torch.Tensor] = None) -> dict:
+        """batch: (2B,3,H,W) = [view1; view2] on the device; spacing2b: (2B,3) or None.
+        Returns device tensors {loss, dino, gram, grad_norm_sq} and the python float lr (no sync)."""
+        hp = self.hp
+        lr = get_lr(self.step_count, hp.max_steps, hp.warmup_steps, hp.lr, hp.min_lr)
+        self.flat_g.zero_()
+        self.bucketer.arm()
+        with ops.compute_dtype(self.compute_dtype):
+            s_feats = self.student.backbone(batch, spacing=spacing2b)
+            with torch.no_grad():
+                t_feats = self.teacher.backbone(batch, spacing=spacing2b)
+                t_out = self.teacher.head(t_feats[:, 0])
+            s_out = self.student.head(s_feats[:, 0])
+            l_dino = ops.DinoCEFn.apply(s_out, t_out, self.center, hp.student_temp, hp.teacher_temp)
+            # centre EMA after the loss used the old centre; batch mean is global under DP
+            bm = all_reduce_mean_(ops.colmean(t_out), self.group)
+            ops.center_ema_(self.center.view(-1), bm, hp.center_momentum)
+            if hp.gram_weight != 0.0:
+                l_gram = ops.GramLossFn.apply(s_feats, t_feats)
+                loss = l_dino + hp.gram_weight * l_gram
+            else:
+                l_gram = torch.zeros((), device=batch.device)
+                loss = l_dino
+            loss.backward()
+        self.bucketer.finish()
+        self.opt_steps += 1
+        gsq = ops.adamw_ema_(self.flat_p, self.flat_g, self.adam_m, self.adam_v, self.flat_t, lr=lr,
+                             weight_decay=hp.weight_decay, beta1=hp.beta1, beta2=hp.beta2, eps=hp.adam_eps,
+                             step_t=self.opt_steps, ema=hp.ema, grad_scale=1.0 / self.world)
+        ops.weight_cache.clear()     # master weights changed under the bf16 copies
+        self.step_count += 1
+        self.last = {"loss": loss.detach(), "dino": l_dino.detach(), "gram": l_gram.detach(), "grad_norm_sq": gsq, "lr": lr}
+        return self.last
+
+    # -- convenience ------------------------------------------------------------------------------
+    def scalars(self) -> dict:
+        """Host copies of the last step's scalars (this is the only place that synchronises)."""
+        r = self.last
+        return {"loss": float(r["loss"]), "dino": float(r["dino"]), "gram": float(r["gram"]),
+                "grad_norm": float(r["grad_norm_sq"]) ** 0.5, "lr": r["lr"]}

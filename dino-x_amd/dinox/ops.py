@@ -1,0 +1,597 @@
+"""Host-side wrappers of the C ABI: tensor -> pointer plumbing and autograd glue.
+
+Every function here enqueues hand-written HIP kernels from libdinox_hip.so on torch's current
+stream.  PyTorch is used for device memory (its caching allocator owns every buffer), streams and
+the autograd graph only.  Tensors must live on a CUDA(HIP) device: CPU tensors raise -- the product
+has no CPU fallback (the CPU restatement lives in oracle/ and is test infrastructure).
+
+Numeric modes (see include/dinox.h): fp32 "parity" mode and bf16 "throughput" mode.  The mode is
+taken from an explicit override (``compute_dtype(...)`` context manager) or, like the reference's
+``--amp`` path (scripts/phase5_big_run.py:1716-1717), from the ambient ``torch.autocast`` state.
+"""
+from __future__ import annotations
+
+import contextlib
+import ctypes as C
+import math
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import BF16, EPI_ACCUM, EPI_BIAS, EPI_DGELU, EPI_GELU, EPI_RESIDUAL, F32, GemmArgs, check, lib
+
+Tensor = torch.Tensor
+_OVERRIDE: list = []
+
+
+# ------------------------------------------------------------------------------------------
+# mode / plumbing helpers
+# ------------------------------------------------------------------------------------------
+@contextlib.contextmanager
+def compute_dtype(dtype: torch.dtype):
+    """Force the numeric mode (torch.float32 or torch.bfloat16) regardless of autocast state."""
+    if dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("compute dtype must be torch.float32 or torch.bfloat16")
+    _OVERRIDE.append(dtype)
+    try:
+        yield
+    finally:
+        _OVERRIDE.pop()
+
+
+def current_dtype() -> torch.dtype:
+    if _OVERRIDE:
+        return _OVERRIDE[-1]
+    if torch.is_autocast_enabled("cuda"):
+        dt = torch.get_autocast_dtype("cuda")
+        if dt != torch.bfloat16:
+            raise RuntimeError(f"the HIP path supports bfloat16 autocast only (got {dt}); use --amp-dtype bfloat16")
+        return torch.bfloat16
+    return torch.float32
+
+
+def _code(dtype: torch.dtype) -> int:
+    if dtype == torch.float32:
+        return F32
+    if dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported dtype {dtype}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _need_cuda(*ts: Tensor) -> None:
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "dinox: tensors must be on a CUDA/HIP device -- the MI355X kernel library is the only compute "
+                "path (no CPU fallback). Move the model and inputs to 'cuda'.")
+
+
+def _c(t: Tensor) -> Tensor:
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ------------------------------------------------------------------------------------------
+# raw ops (no autograd)
+# ------------------------------------------------------------------------------------------
+def gemm(A: Tensor, B: Tensor, *, transA=False, transB=False, out: Optional[Tensor] = None,
+         out_dtype: Optional[torch.dtype] = None, bias: Optional[Tensor] = None, gelu=False, aux: Optional[Tensor] = None,
+         dgelu=False, residual: Optional[Tensor] = None, accumulate=False, alpha: float = 1.0) -> Tensor:
+    """C = epilogue(alpha * op(A) op(B)^T); A: [M,K] (or [K,M] if transA), B: [N,K] (or [K,N] if transB).
+    3-D operands are batched over dim 0 (B may be 2-D = shared)."""
+    _need_cuda(A, B)
+    assert A.dtype == B.dtype, (A.dtype, B.dtype)
+    A, B = _c(A), _c(B)
+    batched = A.dim() == 3
+    if batched:
+        batch = A.shape[0]
+        a2, b2 = A.shape[1:], (B.shape[1:] if B.dim() == 3 else B.shape)
+    else:
+        batch, a2, b2 = 1, A.shape, B.shape
+    M, K = (a2[1], a2[0]) if transA else (a2[0], a2[1])
+    N, Kb = (b2[1], b2[0]) if transB else (b2[0], b2[1])
+    assert K == Kb, f"inner dims differ: {tuple(A.shape)} vs {tuple(B.shape)} (transA={transA}, transB={transB})"
+    odt = out_dtype or (out.dtype if out is not None else A.dtype)
+    if out is None:
+        out = torch.empty((batch, M, N) if batched else (M, N), dtype=odt, device=A.device)
+    else:
+        assert out.is_contiguous() and out.dtype == odt and out.numel() == batch * M * N
+    epi = 0
+    if bias is not None:
+        epi |= EPI_BIAS
+        assert bias.dtype == torch.float32 and bias.numel() == N
+    if gelu:
+        epi |= EPI_GELU
+    if dgelu:
+        epi |= EPI_DGELU
+        assert aux is not None
+    if aux is not None:
+        assert aux.dtype == odt and aux.is_contiguous() and aux.numel() == batch * M * N
+    if residual is not None:
+        epi |= EPI_RESIDUAL
+        assert residual.dtype == torch.float32 and residual.is_contiguous() and residual.numel() == batch * M * N
+    if accumulate:
+        epi |= EPI_ACCUM
+    g = GemmArgs(
+        A=_p(A), B=_p(B), C=_p(out), M=M, N=N, K=K, lda=a2[1], ldb=b2[1], ldc=N, batch=batch,
+        strideA=a2[0] * a2[1] if batched else 0, strideB=(b2[0] * b2[1] if (batched and B.dim() == 3) else 0),
+        strideC=M * N, transA=int(transA), transB=int(transB), in_dtype=_code(A.dtype), out_dtype=_code(odt),
+        epilogue=epi, alpha=alpha, bias=_p(bias), residual=_p(residual), ldr=N, aux=_p(aux), ldaux=N)
+    check(lib.dinox_gemm(C.byref(g), _stream()), "dinox_gemm")
+    return out
+
+
+def colsum(x: Tensor, out: Optional[Tensor] = None, accumulate=False) -> Tensor:
+    x2 = _c(x).reshape(-1, x.shape[-1])
+    if out is None:
+        out = torch.empty(x2.shape[1], dtype=torch.float32, device=x.device)
+    check(lib.dinox_colsum(_p(x2), _p(out), x2.shape[0], x2.shape[1], x2.shape[1], _code(x.dtype), int(accumulate), _stream()), "dinox_colsum")
+    return out
+
+
+def cast_bf16(x: Tensor) -> Tensor:
+    x = _c(x)
+    out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    check(lib.dinox_cast_bf16(_p(x), _p(out), x.numel(), _stream()), "dinox_cast_bf16")
+    return out
+
+
+def cast_transpose_bf16(w: Tensor) -> Tensor:
+    w = _c(w)
+    R, Cc = w.shape
+    out = torch.empty((Cc, R), dtype=torch.bfloat16, device=w.device)
+    check(lib.dinox_cast_transpose_bf16(_p(w), _p(out), R, Cc, _stream()), "dinox_cast_transpose_bf16")
+    return out
+
+
+def to_mode(x: Tensor, dt: torch.dtype) -> Tensor:
+    """Bring an activation to the GEMM operand dtype of the current mode."""
+    if x.dtype == dt:
+        return _c(x)
+    if dt == torch.bfloat16 and x.dtype == torch.float32:
+        return cast_bf16(x)
+    if dt == torch.float32 and x.dtype == torch.bfloat16:
+        return x.float()
+    raise TypeError(f"cannot bring {x.dtype} to {dt}")
+
+
+class _WeightCache:
+    """bf16 (and transposed bf16) copies of fp32 master weights, keyed by storage + version so the
+    student forward, its backward and repeated teacher forwards of one step share one cast."""
+
+    def __init__(self) -> None:
+        self.d: dict = {}
+
+    def clear(self) -> None:
+        self.d.clear()
+
+    def get(self, w: Tensor, transposed: bool) -> Tensor:
+        key = (w.data_ptr(), w._version, tuple(w.shape), transposed)
+        hit = self.d.get(key)
+        if hit is None:
+            if len(self.d) > 4096:
+                self.d.clear()
+            w2 = w.detach().reshape(w.shape[0], -1)
+            hit = cast_transpose_bf16(w2) if transposed else cast_bf16(w2)
+            self.d[key] = hit
+        return hit
+
+
+weight_cache = _WeightCache()
+
+
+def weight_operand(w: Tensor, dt: torch.dtype, transposed=False) -> Tensor:
+    """W as [N,K] (or W^T as [K,N] when transposed) in the GEMM operand dtype."""
+    w2 = w.detach().reshape(w.shape[0], -1)
+    if dt == torch.float32:
+        return w2 if not transposed else w2  # fp32 kernels take either layout through the trans flags
+    return weight_cache.get(w, transposed)
+
+
+def layernorm_fwd(x: Tensor, w: Tensor, b: Tensor, out_dtype: torch.dtype, eps: float = 1e-5):
+    _need_cuda(x, w, b)
+    assert x.dtype == torch.float32
+    x = _c(x)
+    D = x.shape[-1]
+    rows = x.numel() // D
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    check(lib.dinox_layernorm_fwd(_p(x), _p(w), _p(b), _p(y), _p(mean), _p(rstd), rows, D, eps, _code(out_dtype), _stream()), "dinox_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy: Tensor, x: Tensor, w: Tensor, mean: Tensor, rstd: Tensor, dx: Optional[Tensor] = None,
+                  accumulate=False, want_lowp=False):
+    dy, x = _c(dy), _c(x)
+    D = x.shape[-1]
+    rows = x.numel() // D
+    if dx is None:
+        assert not accumulate
+        dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    dw = torch.empty(D, dtype=torch.float32, device=x.device)
+    db = torch.empty(D, dtype=torch.float32, device=x.device)
+    lowp = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if want_lowp else None
+    ws = torch.empty(lib.dinox_layernorm_bwd_ws_bytes(rows, D), dtype=torch.uint8, device=x.device)
+    check(lib.dinox_layernorm_bwd(_p(dy), _p(x), _p(w), _p(mean), _p(rstd), _p(dx), _p(lowp), _p(dw), _p(db), _p(ws), rows, D,
+                                  _code(dy.dtype), int(accumulate), _stream()), "dinox_layernorm_bwd")
+    return dx, dw, db, lowp
+
+
+def attention_fwd(qkv: Tensor, heads: int):
+    _need_cuda(qkv)
+    qkv = _c(qkv)
+    B, N, C3 = qkv.shape
+    Cc = C3 // 3
+    d = Cc // heads
+    o = torch.empty((B, N, Cc), dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty((B, heads, N), dtype=torch.float32, device=qkv.device)
+    check(lib.dinox_attention_fwd(_p(qkv), _p(o), _p(lse), B, N, heads, d, _code(qkv.dtype), _stream()), "dinox_attention_fwd")
+    return o, lse
+
+
+def attention_bwd(do: Tensor, qkv: Tensor, o: Tensor, lse: Tensor, heads: int) -> Tensor:
+    do = to_mode(do, qkv.dtype)
+    B, N, C3 = qkv.shape
+    d = C3 // 3 // heads
+    dqkv = torch.empty_like(qkv)
+    check(lib.dinox_attention_bwd(_p(do), _p(qkv), _p(o), _p(lse), _p(dqkv), B, N, heads, d, _code(qkv.dtype), _stream()), "dinox_attention_bwd")
+    return dqkv
+
+
+# ------------------------------------------------------------------------------------------
+# autograd functions
+# ------------------------------------------------------------------------------------------
+class LayerNormFn(torch.autograd.Function):
+    """nn.LayerNorm over the fp32 residual stream (reference zoo/arch.py:89,91,187)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, out_dtype, eps):
+        y, mean, rstd = layernorm_fwd(x, w, b, out_dtype, eps)
+        ctx.save_for_backward(x, w, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, mean, rstd = ctx.saved_tensors
+        dx, dw, db, _ = layernorm_bwd(dy, x, w, mean, rstd)
+        return dx, dw, db, None, None
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x W^T + b (+ residual), nn.Linear semantics (reference zoo/arch.py:40-41,46,53)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, residual, out_dtype):
+        _need_cuda(x, w)
+        dt = current_dtype()
+        xm = to_mode(x, dt)
+        K = xm.shape[-1]
+        x2 = xm.reshape(-1, K)
+        odt = torch.float32 if residual is not None else (out_dtype or dt)
+        y = gemm(x2, weight_operand(w, dt), bias=b, residual=None if residual is None else _c(residual).reshape(-1, w.shape[0]),
+                 out_dtype=odt)
+        ctx.save_for_backward(x2, w)
+        ctx.dt, ctx.has_bias, ctx.has_res, ctx.xshape, ctx.xdtype = dt, b is not None, residual is not None, x.shape, x.dtype
+        return y.reshape(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        dt = ctx.dt
+        dy2 = to_mode(dy.reshape(-1, w.shape[0]), dt)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            if dt == torch.float32:
+                dx = gemm(dy2, w.detach(), transB=True, out_dtype=ctx.xdtype)            # dy [M,N] . W [N,K]
+            else:
+                dx = gemm(dy2, weight_operand(w, dt, transposed=True), out_dtype=ctx.xdtype if ctx.xdtype == dt else dt)
+                if dx.dtype != ctx.xdtype:
+                    dx = dx.to(ctx.xdtype)
+            dx = dx.reshape(ctx.xshape)
+        if ctx.needs_input_grad[1]:
+            dw = gemm(dy2, x2, transA=True, transB=True, out_dtype=torch.float32)        # dy^T [N,M] . x [M,K]
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = colsum(dy2)
+        dres = dy if ctx.has_res else None
+        return dx, dw, db, dres, None
+
+
+class MlpFn(torch.autograd.Function):
+    """fc2(GELU_erf(fc1(x))) (+ residual) with GELU / GELU' fused into the GEMM epilogues
+    (reference zoo/arch.py:71-76; also the DINO head, zoo/arch.py:252-256)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, residual, out_dtype):
+        _need_cuda(x, w1, w2)
+        dt = current_dtype()
+        xm = to_mode(x, dt)
+        x2 = xm.reshape(-1, xm.shape[-1])
+        M, H = x2.shape[0], w1.shape[0]
+        pre = torch.empty((M, H), dtype=dt, device=x.device) if any(ctx.needs_input_grad[:5]) else None
+        act = gemm(x2, weight_operand(w1, dt), bias=b1, gelu=True, aux=pre, out_dtype=dt)
+        odt = torch.float32 if residual is not None else (out_dtype or dt)
+        y = gemm(act, weight_operand(w2, dt), bias=b2, residual=None if residual is None else _c(residual).reshape(M, w2.shape[0]),
+                 out_dtype=odt)
+        ctx.save_for_backward(x2, w1, w2, pre, act)
+        ctx.dt, ctx.has_res, ctx.xshape, ctx.xdtype = dt, residual is not None, x.shape, x.dtype
+        ctx.has_b1, ctx.has_b2 = b1 is not None, b2 is not None
+        return y.reshape(*x.shape[:-1], w2.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w1, w2, pre, act = ctx.saved_tensors
+        dt = ctx.dt
+        dy2 = to_mode(dy.reshape(-1, w2.shape[0]), dt)
+        if dt == torch.float32:
+            dpre = gemm(dy2, w2.detach(), transB=True, dgelu=True, aux=pre, out_dtype=dt)
+        else:
+            dpre = gemm(dy2, weight_operand(w2, dt, transposed=True), dgelu=True, aux=pre, out_dtype=dt)
+        dw2 = gemm(dy2, act, transA=True, transB=True, out_dtype=torch.float32)
+        db2 = colsum(dy2) if ctx.has_b2 else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if dt == torch.float32:
+                dx = gemm(dpre, w1.detach(), transB=True, out_dtype=dt)
+            else:
+                dx = gemm(dpre, weight_operand(w1, dt, transposed=True), out_dtype=dt)
+            if dx.dtype != ctx.xdtype:
+                dx = dx.to(ctx.xdtype)
+            dx = dx.reshape(ctx.xshape)
+        dw1 = gemm(dpre, x2, transA=True, transB=True, out_dtype=torch.float32)
+        db1 = colsum(dpre) if ctx.has_b1 else None
+        return dx, dw1, db1, dw2, db2, (dy if ctx.has_res else None), None
+
+
+class AttentionCoreFn(torch.autograd.Function):
+    """softmax(Q K^T / sqrt(d)) V on the packed qkv tensor (reference zoo/arch.py:45-52)."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads):
+        o, lse = attention_fwd(qkv, heads)
+        ctx.save_for_backward(qkv, o, lse)
+        ctx.heads = heads
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, o, lse = ctx.saved_tensors
+        return attention_bwd(do, qkv, o, lse, ctx.heads), None
+
+
+_UNFOLD_CACHE: dict = {}
+
+
+def patch_unfold(x: Tensor, patch: int, dt: torch.dtype) -> Tensor:
+    """[V,3,H,W] fp32 -> [V*P, 3*p*p] in dt; cached per input batch so that student and teacher,
+    which see the same batch (scripts/phase5_big_run.py:1741-1743), share one unfold."""
+    _need_cuda(x)
+    x = _c(x)
+    if x.dtype != torch.float32:
+        x = x.float()
+    key = (x.data_ptr(), x._version, tuple(x.shape), patch, dt)
+    hit = _UNFOLD_CACHE.get("k")
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    V, Cn, H, W = x.shape
+    assert Cn == 3, "2.5D slice stacks have 3 channels"
+    u = torch.empty((V * (H // patch) * (W // patch), 3 * patch * patch), dtype=dt, device=x.device)
+    check(lib.dinox_patch_unfold(_p(x), _p(u), V, H, W, patch, _code(dt), _stream()), "dinox_patch_unfold")
+    _UNFOLD_CACHE["k"] = (key, u)
+    return u
+
+
+class TokensFn(torch.autograd.Function):
+    """patch-embed conv (as GEMM) + [CLS|patches] + pos (+scale) + registers (reference zoo/arch.py:216-229)."""
+
+    @staticmethod
+    def forward(ctx, x, pw, pb, cls, pos, regs, scale, patch):
+        dt = current_dtype()
+        u = patch_unfold(x, patch, dt)
+        V = x.shape[0]
+        D = pw.shape[0]
+        P = u.shape[0] // V
+        R = 0 if regs is None else regs.shape[1]
+        patches = gemm(u, weight_operand(pw, dt), bias=pb, out_dtype=dt)
+        tokens = torch.empty((V, 1 + P + R, D), dtype=torch.float32, device=x.device)
+        sc = None if scale is None else _c(scale).reshape(V, D)
+        check(lib.dinox_tokens_fwd(_p(patches), _p(_c(cls)), _p(_c(pos)), _p(None if regs is None else _c(regs)), _p(sc), _p(tokens),
+                                   V, P, R, D, _code(dt), _stream()), "dinox_tokens_fwd")
+        ctx.save_for_backward(u)
+        ctx.dims, ctx.dt, ctx.has_scale, ctx.pw_shape = (V, P, R, D), dt, scale is not None, pw.shape
+        return tokens
+
+    @staticmethod
+    def backward(ctx, dtok):
+        (u,) = ctx.saved_tensors
+        V, P, R, D = ctx.dims
+        dt = ctx.dt
+        dtok = _c(dtok)
+        dev = dtok.device
+        dpatches = torch.empty((V * P, D), dtype=dt, device=dev)
+        dcls = torch.empty((1, 1, D), dtype=torch.float32, device=dev)
+        dpos = torch.empty((1, 1 + P, D), dtype=torch.float32, device=dev)
+        dregs = torch.empty((1, R, D), dtype=torch.float32, device=dev) if R else None
+        dscale = torch.empty((V, 1, D), dtype=torch.float32, device=dev) if ctx.has_scale else None
+        check(lib.dinox_tokens_bwd(_p(dtok), _p(dpatches), _p(dcls), _p(dpos), _p(dregs), _p(dscale), V, P, R, D, _code(dt), _stream()),
+              "dinox_tokens_bwd")
+        dw = gemm(dpatches, u, transA=True, transB=True, out_dtype=torch.float32).reshape(ctx.pw_shape)
+        db = colsum(dpatches)
+        return None, dw, db, dcls, dpos, dregs, dscale, None
+
+
+class ScaleEmbedFn(torch.autograd.Function):
+    """ScaleEmbedding MLP (reference zoo/arch.py:119-140), fp32, fused per row."""
+
+    @staticmethod
+    def forward(ctx, spacing, w0, b0, w2, b2, lnw, lnb, eps):
+        _need_cuda(spacing, w0)
+        sp = _c(spacing.float())
+        V, h, D = sp.shape[0], w0.shape[0], w2.shape[0]
+        dev = sp.device
+        out = torch.empty((V, 1, D), dtype=torch.float32, device=dev)
+        hpre = torch.empty((V, h), dtype=torch.float32, device=dev)
+        e = torch.empty((V, D), dtype=torch.float32, device=dev)
+        mean = torch.empty(V, dtype=torch.float32, device=dev)
+        rstd = torch.empty(V, dtype=torch.float32, device=dev)
+        check(lib.dinox_scale_embed_fwd(_p(sp), _p(_c(w0)), _p(b0), _p(_c(w2)), _p(b2), _p(lnw), _p(lnb), _p(out), _p(hpre), _p(e),
+                                        _p(mean), _p(rstd), V, h, D, eps, _stream()), "dinox_scale_embed_fwd")
+        ctx.save_for_backward(sp, w0, w2, lnw, hpre, e, mean, rstd)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        sp, w0, w2, lnw, hpre, e, mean, rstd = ctx.saved_tensors
+        V, h, D = sp.shape[0], w0.shape[0], w2.shape[0]
+        dev = sp.device
+        f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        dw0, db0, dw2, db2, dlnw, dlnb = f(h, 3), f(h), f(D, h), f(D), f(D), f(D)
+        dsp = f(V, 3) if ctx.needs_input_grad[0] else None
+        ws = torch.empty(lib.dinox_scale_embed_bwd_ws_bytes(V, h, D), dtype=torch.uint8, device=dev)
+        check(lib.dinox_scale_embed_bwd(_p(_c(dout)), _p(sp), _p(_c(w0)), _p(_c(w2)), _p(lnw), _p(hpre), _p(e), _p(mean), _p(rstd),
+                                        _p(dw0), _p(db0), _p(dw2), _p(db2), _p(dlnw), _p(dlnb), _p(dsp), _p(ws), V, h, D, _stream()),
+              "dinox_scale_embed_bwd")
+        return dsp, dw0, db0, dw2, db2, dlnw, dlnb, None
+
+
+def dino_ce(s: Tensor, t: Tensor, center: Tensor, student_temp: float, teacher_temp: float, want_grad: bool, grad_scale: float = 1.0):
+    """Returns (loss[1], ds or None).  s, t: [2B, K]."""
+    _need_cuda(s, t, center)
+    s, t = _c(s.float()), _c(t.float())
+    rows, K = s.shape
+    loss = torch.empty(1, dtype=torch.float32, device=s.device)
+    row_loss = torch.empty(rows, dtype=torch.float32, device=s.device)
+    ds = torch.empty_like(s) if want_grad else None
+    check(lib.dinox_dino_ce(_p(s), _p(t), _p(_c(center).reshape(-1)), student_temp, teacher_temp, grad_scale, _p(loss), _p(ds), _p(row_loss),
+                            rows, K, _stream()), "dinox_dino_ce")
+    return loss, ds
+
+
+class DinoCEFn(torch.autograd.Function):
+    """DINO centring/sharpening cross-entropy (reference scripts/phase5_big_run.py:692-717)."""
+
+    @staticmethod
+    def forward(ctx, s, t, center, student_temp, teacher_temp):
+        loss, ds = dino_ce(s, t, center, student_temp, teacher_temp, ctx.needs_input_grad[0])
+        ctx.save_for_backward(ds)
+        ctx.sdtype = s.dtype
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (ds,) = ctx.saved_tensors
+        return (ds * g).to(ctx.sdtype), None, None, None, None
+
+
+def colmean(t: Tensor) -> Tensor:
+    t = _c(t.float())
+    out = torch.empty(t.shape[1], dtype=torch.float32, device=t.device)
+    check(lib.dinox_colmean(_p(t), _p(out), t.shape[0], t.shape[1], _stream()), "dinox_colmean")
+    return out
+
+
+def center_ema_(center: Tensor, batch_mean: Tensor, momentum: float) -> None:
+    assert center.is_contiguous() and center.dtype == torch.float32
+    check(lib.dinox_center_ema(_p(center), _p(batch_mean), momentum, center.numel(), _stream()), "dinox_center_ema")
+
+
+def gram_loss_fwd(sf: Tensor, tf: Tensor, dt: torch.dtype):
+    """Returns (loss[1], saved) with saved = (diff [V,T,T] fp32, shat, snorm) for backward."""
+    _need_cuda(sf, tf)
+    sf, tf = _c(sf.float()), _c(tf.float())
+    V, N, D = sf.shape
+    T = N - 1
+    dev = sf.device
+    cat = torch.empty((V, T, 2 * D), dtype=dt, device=dev)
+    catneg = torch.empty((V, T, 2 * D), dtype=dt, device=dev)
+    shat = torch.empty((V, T, D), dtype=dt, device=dev)
+    snorm = torch.empty((V, T), dtype=torch.float32, device=dev)
+    check(lib.dinox_gram_normalize(_p(sf), _p(tf), _p(cat), _p(catneg), _p(shat), _p(snorm), V, N, D, _code(dt), _stream()), "dinox_gram_normalize")
+    diff = gemm(cat, catneg, out_dtype=torch.float32)          # [V,T,T] = Gs - Gt in one batched NT GEMM (K = 2D)
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    ws = torch.empty(1024, dtype=torch.float32, device=dev)
+    check(lib.dinox_sqsum(_p(diff), diff.numel(), 1.0 / float(V * T * T), _p(loss), _p(ws), _stream()), "dinox_sqsum")
+    return loss, (diff, shat, snorm)
+
+
+def gram_loss_bwd(saved, sf_shape, scale: float, dfeats: Optional[Tensor] = None, accumulate=False) -> Tensor:
+    diff, shat, snorm = saved
+    V, N, D = sf_shape
+    T = N - 1
+    dt = shat.dtype
+    d_in = diff if dt == torch.float32 else cast_bf16(diff)
+    # dXh = (4*scale/(V T^2)) * diff . Xh ; diff is symmetric, so it is also the [K=u][M=t] operand of a TN product
+    dxh = gemm(d_in, shat, transA=True, transB=True, out_dtype=torch.float32, alpha=4.0 * scale / float(V * T * T))
+    if dfeats is None:
+        dfeats = torch.zeros((V, N, D), dtype=torch.float32, device=diff.device)
+    check(lib.dinox_gram_normalize_bwd(_p(dxh), _p(shat), _p(snorm), None, _p(dfeats), V, N, D, _code(dt), int(accumulate), _stream()),
+          "dinox_gram_normalize_bwd")
+    return dfeats
+
+
+class GramLossFn(torch.autograd.Function):
+    """Gram-anchoring loss (reference scripts/phase5_big_run.py:723-739)."""
+
+    @staticmethod
+    def forward(ctx, sf, tf):
+        dt = current_dtype()
+        loss, saved = gram_loss_fwd(sf, tf, dt)
+        ctx.save_for_backward(*saved)
+        ctx.shape = tuple(sf.shape)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        d = gram_loss_bwd(ctx.saved_tensors, ctx.shape, 1.0)
+        return d * g, None
+
+
+def adamw_ema_(p: Tensor, g: Tensor, m: Tensor, v: Tensor, teacher: Optional[Tensor], *, lr: float, weight_decay: float,
+               beta1: float, beta2: float, eps: float, step_t: int, ema: float, grad_scale: float = 1.0) -> Tensor:
+    """Fused grad-norm + AdamW + EMA over flat fp32 arenas; returns gnorm_sq[1] (device)."""
+    _need_cuda(p, g, m, v)
+    for t in (p, g, m, v) + ((teacher,) if teacher is not None else ()):
+        assert t.is_contiguous() and t.dtype == torch.float32 and t.numel() == p.numel()
+    out = torch.empty(1, dtype=torch.float32, device=p.device)
+    ws = torch.empty(4096, dtype=torch.float32, device=p.device)
+    check(lib.dinox_adamw_ema(_p(p), _p(g), _p(m), _p(v), _p(teacher), p.numel(), lr, weight_decay, beta1, beta2, eps, step_t, ema,
+                              grad_scale, _p(out), _p(ws), _stream()), "dinox_adamw_ema")
+    return out
+
+
+def sumsq(x: Tensor) -> Tensor:
+    x = _c(x)
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    ws = torch.empty(4096, dtype=torch.float32, device=x.device)
+    check(lib.dinox_sumsq(_p(x), x.numel(), _p(out), _p(ws), _stream()), "dinox_sumsq")
+    return out
+
+
+class GeluFn(torch.autograd.Function):
+    """Stand-alone exact-erf GELU (fp32 math) for module paths that cannot use the fused epilogue."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _need_cuda(x)
+        xf = _c(x.float())
+        y = torch.empty_like(xf)
+        check(lib.dinox_gelu_fwd(_p(xf), _p(y), xf.numel(), _stream()), "dinox_gelu_fwd")
+        ctx.save_for_backward(xf)
+        ctx.xdtype = x.dtype
+        return y.to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (xf,) = ctx.saved_tensors
+        dyf = _c(dy.float())
+        dx = torch.empty_like(xf)
+        check(lib.dinox_gelu_bwd(_p(dyf), _p(xf), _p(dx), xf.numel(), _stream()), "dinox_gelu_bwd")
+        return dx.to(ctx.xdtype)

@@ -1,0 +1,209 @@
+/* dinox.h -- C ABI of libdinox_hip.so, the MI355X (gfx950) kernel library for the DINO-X hot path.
+ *
+ * The reference (timlawrenz/DINO-X) has no FFI or operator registry: every op on its hot path is
+ * an ATen call made from Python.  The drop-in seam is therefore the Python
+ * module surface (zoo.arch / zoo.hub / zoo.encode / scripts/phase5_big_run.py), and this header is
+ * the boundary *underneath* it: one entry point per ATen call sequence that the reference issues
+ * on the path.  Each entry cites the reference lines it replaces (paths relative to the reference
+ * checkout).  INTEGRATION.md shows the ctypes binding a reference maintainer would add.
+ *
+ * Conventions (all entries):
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless it says "host";
+ *   - the caller allocates and owns every buffer, including workspaces (sizes via *_ws_bytes);
+ *   - kernels are enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream);
+ *     no entry synchronises, allocates or frees, so every entry is hipGraph-capturable;
+ *   - return 0 on success, a negative DINOX_E* code on bad arguments, or the positive
+ *     hipError_t of a failed launch; the message is kept per thread for dinox_last_error();
+ *   - re-entrant from any host thread (autograd's backward thread included): no mutable globals;
+ *   - dtype codes: activations/weights may be fp32 ("parity mode", exact-fp32 MFMA / VALU) or
+ *     bf16 ("throughput mode": bf16 MFMA operands, fp32 accumulation); the residual stream,
+ *     LayerNorm statistics, softmax, losses, gradients of parameters and optimiser state are
+ *     always fp32, mirroring what torch.autocast does on the reference path.
+ */
+#ifndef DINOX_H
+#define DINOX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DINOX_ABI_VERSION 1
+
+/* dtype codes */
+#define DINOX_F32 0
+#define DINOX_BF16 1
+
+/* error codes (negative); positive returns are hipError_t values */
+#define DINOX_OK 0
+#define DINOX_EINVAL (-1)      /* bad argument (null pointer, non-positive size, ...) */
+#define DINOX_EUNSUPPORTED (-2) /* combination not implemented (e.g. bf16 GEMM with transA!=transB) */
+#define DINOX_EALIGN (-3)      /* pointer / leading dimension not aligned as the bf16 path needs */
+
+int dinox_version(void);
+/* Human-readable description of the last failure on the calling thread ("" if none). */
+const char* dinox_last_error(void);
+/* 1 if device 0 is a gfx950 part and kernels can launch, 0 otherwise (host query, no launch). */
+int dinox_device_ok(void);
+
+/* ------------------------------------------------------------------------------------------
+ * GEMM with fused epilogue -- replaces nn.Linear / nn.Conv2d(k=s=patch) / torch.bmm:
+ *   zoo/arch.py:46 (qkv), :53 (proj), :76 (fc1 -> GELU -> fc2), :216 (patch_embed),
+ *   :253-255 (head), scripts/phase5_big_run.py:727 (Gram bmm), and their autograd backward.
+ *
+ *   C[b][m][n] = epilogue( alpha * sum_k A(b,m,k) * B(b,n,k) )
+ *   transA = 0: A stored [M][K] (K contiguous, lda >= K);  1: A stored [K][M] (lda >= M)
+ *   transB = 0: B stored [N][K] (nn.Linear weight layout, ldb >= K);  1: B stored [K][N]
+ *   in_dtype applies to A and B; out_dtype to C and aux.  bf16 inputs support (0,0) "NT" and
+ *   (1,1) "TN" only (pre-transposed bf16 weight copies make every hot-path product one of them).
+ *
+ * epilogue bits (applied in this order):
+ *   BIAS      acc += bias[n]                       (fp32 [N])
+ *   GELU      if aux: aux = acc (pre-activation, out_dtype, ld = ldaux); acc = gelu_erf(acc)
+ *   DGELU     acc *= gelu_erf'(aux[m][n])          (aux read, out_dtype)
+ *   RESIDUAL  acc += residual[m][n]                (fp32, ld = ldr)
+ *   ACCUM     C += acc instead of C = acc          (fp32 C only)
+ * ------------------------------------------------------------------------------------------ */
+#define DINOX_EPI_BIAS 1
+#define DINOX_EPI_GELU 2
+#define DINOX_EPI_DGELU 4
+#define DINOX_EPI_RESIDUAL 8
+#define DINOX_EPI_ACCUM 16
+
+typedef struct dinox_gemm_args {
+  const void* A;
+  const void* B;
+  void* C;
+  int64_t M, N, K;
+  int64_t lda, ldb, ldc;
+  int64_t batch;                       /* >= 1 */
+  int64_t strideA, strideB, strideC;   /* elements between batch items (0 = shared operand) */
+  int32_t transA, transB;
+  int32_t in_dtype, out_dtype;
+  int32_t epilogue;
+  float alpha;
+  const float* bias;
+  const float* residual;
+  int64_t ldr;
+  void* aux;
+  int64_t ldaux;
+} dinox_gemm_args;
+
+int dinox_gemm(const dinox_gemm_args* args, void* stream);
+
+/* out[n] (+)= sum_m x[m][n]   -- bias gradients (autograd of nn.Linear bias, zoo/arch.py:40-41,71-73). */
+int dinox_colsum(const void* x, float* out, int64_t M, int64_t N, int64_t ldx, int dtype, int accumulate,
+                 void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * LayerNorm -- replaces nn.LayerNorm(D), eps 1e-5, affine (zoo/arch.py:89,91,126,187; calls :95,96,237).
+ * x is the fp32 residual stream; y is written in out_dtype (bf16 when it only feeds a GEMM).
+ * bwd: dx (=|+=) LN'(dy);  dw, db overwritten.  ws: dinox_layernorm_bwd_ws_bytes(rows, dim) bytes.
+ *      dx_lowp (optional, may be NULL): bf16 copy of the final dx -- the residual-stream gradient is the
+ *      dY operand of the next backward GEMMs, which autocast rounds to bf16 at that point as well.
+ * ------------------------------------------------------------------------------------------ */
+int dinox_layernorm_fwd(const float* x, const float* w, const float* b, void* y, float* mean, float* rstd,
+                        int64_t rows, int dim, float eps, int out_dtype, void* stream);
+int64_t dinox_layernorm_bwd_ws_bytes(int64_t rows, int dim);
+int dinox_layernorm_bwd(const void* dy, const float* x, const float* w, const float* mean, const float* rstd,
+                        float* dx, void* dx_lowp, float* dw, float* db, void* ws, int64_t rows, int dim,
+                        int dy_dtype, int accumulate_dx, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-head self-attention core -- replaces the reshape/permute/unbind +
+ * F.scaled_dot_product_attention + transpose/reshape of zoo/arch.py:45-52 (scale 1/sqrt(d), no mask).
+ * qkv is the packed output of the qkv Linear, [B][N][3][heads][d]; o is [B][N][heads*d];
+ * lse is the per-row log-sum-exp of the scaled scores, [B][heads][N] fp32 (saved for backward).
+ * bwd recomputes P from lse (flash style); dqkv has the layout of qkv.
+ * ------------------------------------------------------------------------------------------ */
+int dinox_attention_fwd(const void* qkv, void* o, float* lse, int B, int N, int heads, int d, int dtype,
+                        void* stream);
+int dinox_attention_bwd(const void* d_o, const void* qkv, const void* o, const float* lse, void* dqkv,
+                        int B, int N, int heads, int d, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Patch unfold + token assembly -- replaces the im2col half of nn.Conv2d(3,D,k=p,s=p) and
+ * flatten/transpose/cat/+pos_embed/+scale_embed/cat of zoo/arch.py:216-229.
+ * unfold: x fp32 NCHW [V][3][H][W] -> u [V*P][3*p*p] in out_dtype (the A operand of the patch GEMM;
+ *         computed once per step and shared by student and teacher, which see the same batch).
+ * assemble fwd: tokens[v][0] = cls + pos[0] (+scale[v]);  tokens[v][1+i] = patches[v][i] + pos[1+i] (+scale[v]);
+ *               tokens[v][1+P+r] = registers[r].   tokens is the fp32 residual stream [V][N][D].
+ * assemble bwd: dpatches (dtype) for the patch GEMM's dW/db; dcls, dpos, dregs reduced over the batch;
+ *               dscale[v] = sum over the 1+P body tokens (NULL when not scale-aware).
+ * ------------------------------------------------------------------------------------------ */
+int dinox_patch_unfold(const float* x, void* u, int V, int H, int W, int patch, int out_dtype, void* stream);
+int dinox_tokens_fwd(const void* patches, const float* cls, const float* pos, const float* registers,
+                     const float* scale, float* tokens, int V, int P, int R, int D, int patches_dtype,
+                     void* stream);
+int dinox_tokens_bwd(const float* dtokens, void* dpatches, float* dcls, float* dpos, float* dregs,
+                     float* dscale, int V, int P, int R, int D, int patches_dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * ScaleEmbedding -- replaces Linear(3,h) -> GELU -> Linear(h,D) -> LayerNorm(D) (zoo/arch.py:119-140).
+ * All fp32 (V rows only).  fwd saves hpre [V][h], e [V][D] (pre-LN), mean/rstd [V] for backward.
+ * bwd overwrites every parameter gradient and dspacing [V][3] (may be NULL).
+ * ------------------------------------------------------------------------------------------ */
+int dinox_scale_embed_fwd(const float* spacing, const float* w0, const float* b0, const float* w2,
+                          const float* b2, const float* lnw, const float* lnb, float* out, float* hpre,
+                          float* e, float* mean, float* rstd, int V, int h, int D, float eps, void* stream);
+int64_t dinox_scale_embed_bwd_ws_bytes(int V, int h, int D);
+int dinox_scale_embed_bwd(const float* dout, const float* spacing, const float* w0, const float* w2,
+                          const float* lnw, const float* hpre, const float* e, const float* mean,
+                          const float* rstd, float* dw0, float* db0, float* dw2, float* db2, float* dlnw,
+                          float* dlnb, float* dspacing, void* ws, int V, int h, int D, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * DINO centring/sharpening cross-entropy -- replaces DINOLoss.forward/update_center
+ * (scripts/phase5_big_run.py:686-720).  s, t: [2B][K] fp32 logits, rows [view1; view2].
+ *   loss[0] = (1/2B) sum_i -sum_k softmax((t[pair(i)]-center)/tt)[k] * log_softmax(s[i]/ts)[k],
+ *   pair(i) = (i+B) mod 2B;   ds = grad_scale * dloss/ds (NULL to skip);  row_loss: [2B] workspace.
+ * colmean: out[k] = mean_i t[i][k]  (the batch centre; all-reduced across ranks under DP before
+ * dinox_center_ema applies  center = center*m + mean*(1-m), phase5_big_run.py:689-690).
+ * ------------------------------------------------------------------------------------------ */
+int dinox_dino_ce(const float* s, const float* t, const float* center, float student_temp, float teacher_temp,
+                  float grad_scale, float* loss, float* ds, float* row_loss, int rows2B, int K, void* stream);
+int dinox_colmean(const float* t, float* out, int rows, int K, void* stream);
+int dinox_center_ema(float* center, const float* batch_mean, float momentum, int K, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Gram anchoring -- replaces compute_gram_matrix / compute_gram_anchoring_loss
+ * (scripts/phase5_big_run.py:723-739): tokens 1..N-1 (registers included), F.normalize eps 1e-12,
+ * G = Xh Xh^T, mse_loss mean.  The Gram products themselves go through dinox_gemm (batched);
+ * these entries are the fused pieces around it:
+ *   normalize: cat[v][t][0:D] = s_hat, cat[v][t][D:2D] = t_hat; catneg = [s_hat, -t_hat] (in_dtype of
+ *              the GEMM), so that diff = cat * catneg^T = Gs - Gt in ONE batched NT GEMM with K = 2D;
+ *              snorm [V][T] = max(||s||, eps) and a copy of s_hat alone (shat, GEMM dtype) for backward.
+ *   sqsum:     loss[0] = scale * sum(diff^2)   (scale = 1/(V*T*T));  ws: [blocks] fp32, >= 1024 floats.
+ *   normalize_bwd: dfeats[v][1+t] (+)= (dxh - xh (xh.dxh)) / norm  (dxh / eps when ||x|| <= eps);
+ *              dfeats[v][0] untouched (CLS does not enter the Gram loss).
+ * ------------------------------------------------------------------------------------------ */
+int dinox_gram_normalize(const float* sfeats, const float* tfeats, void* cat, void* catneg, void* shat,
+                         float* snorm, int V, int N, int D, int out_dtype, void* stream);
+int dinox_sqsum(const float* x, int64_t n, float scale, float* loss, float* ws, void* stream);
+int dinox_gram_normalize_bwd(const float* dxh, const void* shat, const float* snorm, const float* sfeats,
+                             float* dfeats, int V, int N, int D, int shat_dtype, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Optimiser tail -- replaces the per-parameter grad-norm loop (scripts/phase5_big_run.py:1784-1789),
+ * torch.optim.AdamW.step (:1794; betas .9/.999, eps 1e-8, decoupled decay on EVERY parameter) and the
+ * per-parameter EMA teacher update (:1799-1802) with ONE pass over flat fp32 arenas of n elements.
+ *   g is multiplied by grad_scale first (1/world_size after a sum all-reduce);
+ *   gnorm_sq[0] = sum((grad_scale*g)^2)  (fp32; ws: >= 4096 floats);  teacher may be NULL (no EMA).
+ *   step_t = 1-based optimiser step for the bias corrections.
+ * cast: bf16 copies of weights for the MFMA path (and [C][R] transposed copies for dX products).
+ * ------------------------------------------------------------------------------------------ */
+int dinox_adamw_ema(float* p, const float* g, float* m, float* v, float* teacher, int64_t n, float lr,
+                    float weight_decay, float beta1, float beta2, float eps, int step_t, float ema,
+                    float grad_scale, float* gnorm_sq, float* ws, void* stream);
+int dinox_sumsq(const float* x, int64_t n, float* out, float* ws, void* stream);
+int dinox_cast_bf16(const float* src, void* dst, int64_t n, void* stream);
+int dinox_cast_transpose_bf16(const float* src, void* dst, int R, int C, void* stream);
+/* Elementwise helpers used by the host-side modules: y = gelu_erf(x) / dx = dy * gelu_erf'(x) (fp32). */
+int dinox_gelu_fwd(const float* x, float* y, int64_t n, void* stream);
+int dinox_gelu_bwd(const float* dy, const float* x, float* dx, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DINOX_H */

@@ -21,6 +21,7 @@ Fixtures
   vit_plain.npz       PatchViT 28/14/32/1/2 no registers, not scale-aware: fwd only
   step_tiny.npz       3 consecutive training steps of the reference loop order
                       (phase5_big_run.py:1741-1802) on a 28/14/32/2/2 model
+  init_seed0.npz      raw initial state_dict under torch.manual_seed(0) (28/14/32/2/2 model)
   get_lr.npz          get_lr at a grid of (step,total)
 """
 from __future__ import annotations
@@ -276,6 +277,13 @@ def step_tiny():
     print(f"step_tiny.npz: {os.path.getsize(path) / 1024:.1f} KiB; losses={losses} gn={gns}")
 
 
+def init_seed0():
+    """Raw reference initialisation under torch.manual_seed(0): pins the drop-in's init call sequence."""
+    torch.manual_seed(0)
+    m = A.DinoStudentTeacher(A.PatchViT(img_size=28, patch=14, dim=32, depth=2, heads=2, num_registers=2, scale_aware=True), out_dim=64)
+    save("init_seed0.npz", **sd_arrays("sd", m.state_dict()))
+
+
 def get_lr_grid():
     rows = []
     for total in (None, 10, 5000):
@@ -295,4 +303,5 @@ if __name__ == "__main__":
     vit_tiny()
     vit_plain()
     step_tiny()
+    init_seed0()
     get_lr_grid()

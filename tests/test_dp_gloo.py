@@ -1,0 +1,78 @@
+"""Data-parallel path on CPU: world_size-2 `gloo` process groups exercising dinox/dp.py.
+
+(1) GradBucketer: hooks + bucketed async all-reduce over a flat gradient arena reproduce the
+    single-process gradient of the global batch.
+(2) The DP recipe of SURVEY.md section 8e (shard by sample, sum all-reduce of gradients scaled by
+    1/world, all-reduce of the teacher batch mean for the centre) with the CPU oracle as the compute:
+    the 2-rank result equals the single-process oracle at the global batch.
+Workers are separate OS processes (tests/_dp_workers.py); the oracle is the checker/stand-in compute."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import _dp_workers as W
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(which, tmp_path, world=2):
+    port, out = _free_port(), str(tmp_path / "out.npz")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_dp_workers.py"), which, str(r), str(world), str(port), out],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=150)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            o, _ = p.communicate()
+        logs.append(o.decode(errors="replace")[-2000:])
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    with np.load(out) as z:
+        return {k: z[k] for k in z.files}
+
+
+def test_bucketed_allreduce_matches_global_batch(tmp_path):
+    got = _run("bucketer", tmp_path)
+    from dinox.engine import flatten_parameters
+    model = W.toy()
+    flat_p, params, offs = flatten_parameters(model)
+    X, Y = W.toy_data()
+    ((model(X) - Y) ** 2).mean().backward()
+    want = torch.zeros_like(flat_p)
+    for p, o in zip(params, offs):
+        want[o:o + p.numel()] = p.grad.reshape(-1)
+    assert int(got["nbuckets"]) >= 3
+    np.testing.assert_allclose(got["flat"], want.numpy(), rtol=1e-5, atol=1e-7)
+
+
+def test_two_rank_step_equals_global_batch_oracle(tmp_path):
+    got = _run("dp_oracle", tmp_path)
+    O, cfg, sd, v1, v2, sp, hp = W.oracle_setup()
+    st = O.init_state(cfg, sd)
+    st.center = 0.05 * torch.ones(1, cfg.out_dim)
+    l, _, _, grads, t_out, _ = O.losses_and_grads(st, torch.cat([v1, v2], 0), torch.cat([sp, sp], 0), hp)
+    want = torch.cat([grads[k].reshape(-1) for k in grads]).numpy()
+    assert float(got["loss"]) == pytest.approx(float(l), rel=1e-5)
+    np.testing.assert_allclose(got["flat"], want, rtol=2e-4, atol=2e-5 * float(np.abs(want).max()))   # fp32 summation order
+    np.testing.assert_allclose(got["center"], O.center_update(st.center, t_out, hp.center_momentum).numpy(), rtol=1e-5, atol=1e-7)
+
+
+def test_shard_range_rejects_ragged():
+    from dinox.dp import shard_range
+    assert shard_range(8, 1, 2) == (4, 8)
+    with pytest.raises(ValueError):
+        shard_range(7, 0, 2)

@@ -1,0 +1,429 @@
+"""GPU parity tests (run with ``-m gpu`` on an MI355X): the HIP path, called through the C ABI, against
+the golden fixtures captured from the reference and against the CPU oracle on the same seeded inputs.
+
+Tolerances: fp32 "parity mode" must meet the north-star gate of 1e-3 relative (we assert 1e-4 or
+tighter where fp32 round-off allows); bf16 "throughput mode" is compared by relative L2 error, since
+bf16 has 2^-9 relative precision per element (the reference's --amp path has the same property).
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, sub, t
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def dx():
+    from dinox import ops
+    import zoo.arch as arch
+    import dinox._lib as L
+    assert L.lib.dinox_device_ok() == 1, L.last_error()
+    return ops, arch
+
+
+def rel_l2(a, b):
+    a = torch.as_tensor(a).double().cpu().reshape(-1)
+    b = torch.as_tensor(b).double().cpu().reshape(-1)
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def close(a, b, rtol, atol=0.0, what=""):
+    a = torch.as_tensor(a).double().cpu()
+    b = torch.as_tensor(b).double().cpu()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = (a - b).abs().max().item()
+    scale = b.abs().max().item()
+    assert err <= atol + rtol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e} (rtol {rtol})"
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("tA,tB", [(0, 0), (1, 1), (0, 1), (1, 0)])
+@pytest.mark.parametrize("M,N,K", [(64, 64, 16), (77, 130, 45), (201, 96, 384), (5, 3, 7)])
+def test_gemm_f32_layouts(dx, tA, tB, M, N, K):
+    ops, _ = dx
+    g = torch.Generator().manual_seed(M * 1000 + N * 10 + K)
+    A = torch.randn((K, M) if tA else (M, K), generator=g)
+    B = torch.randn((K, N) if tB else (N, K), generator=g)
+    ref = (A.t() if tA else A).double() @ (B if tB else B.t()).double()
+    out = ops.gemm(A.to(DEV), B.to(DEV), transA=bool(tA), transB=bool(tB))
+    close(out, ref, rtol=2e-6, atol=1e-5, what=f"gemm {tA}{tB}")
+
+
+def test_gemm_f32_epilogues_and_batch(dx):
+    ops, _ = dx
+    g = torch.Generator().manual_seed(5)
+    A, B = torch.randn(3, 50, 40, generator=g), torch.randn(3, 70, 40, generator=g)
+    bias, res = torch.randn(70, generator=g), torch.randn(3, 50, 70, generator=g)
+    pre_ref = torch.einsum("bmk,bnk->bmn", A.double(), B.double()) * 0.5 + bias.double()
+    aux = torch.empty(3, 50, 70, device=DEV)
+    out = ops.gemm(A.to(DEV), B.to(DEV), bias=bias.to(DEV), gelu=True, aux=aux, residual=res.to(DEV), alpha=0.5)
+    gelu = 0.5 * pre_ref * (1 + torch.erf(pre_ref / math.sqrt(2)))
+    close(aux, pre_ref, 1e-5, 1e-5, "aux")
+    close(out, gelu + res.double(), 1e-5, 1e-5, "gelu+res")
+    # DGELU + ACCUM
+    c0 = torch.randn(3, 50, 70, generator=g)
+    out2 = c0.to(DEV).clone()
+    ops.gemm(A.to(DEV), B.to(DEV), out=out2, dgelu=True, aux=aux, accumulate=True)
+    x = pre_ref
+    dg = 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
+    close(out2, c0.double() + torch.einsum("bmk,bnk->bmn", A.double(), B.double()) * dg, 1e-5, 1e-5, "dgelu+accum")
+
+
+@pytest.mark.parametrize("tA,tB,M,N,K", [(0, 0, 256, 384, 384), (0, 0, 201 * 4, 1152, 384), (0, 0, 130, 72, 200),
+                                         (1, 1, 384, 1536, 804), (1, 1, 200, 384, 200), (1, 1, 96, 72, 1000),
+                                         (0, 1, 64, 64, 64), (0, 0, 512, 8192, 384)])
+def test_gemm_bf16_vs_exact(dx, tA, tB, M, N, K):
+    """bf16 operands: products are exact in fp32, so the result must match an fp64 product of the
+    bf16-rounded inputs to fp32-accumulation accuracy, whatever kernel the dispatcher picks."""
+    ops, _ = dx
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn((K, M) if tA else (M, K), generator=g).bfloat16()
+    B = torch.randn((K, N) if tB else (N, K), generator=g).bfloat16()
+    ref = (A.t() if tA else A).double() @ (B if tB else B.t()).double()
+    out = ops.gemm(A.to(DEV), B.to(DEV), transA=bool(tA), transB=bool(tB), out_dtype=torch.float32)
+    close(out, ref, rtol=1e-5, atol=1e-5 * math.sqrt(K), what=f"bf16 gemm {tA}{tB} {M}x{N}x{K}")
+    out_b = ops.gemm(A.to(DEV), B.to(DEV), transA=bool(tA), transB=bool(tB))
+    assert out_b.dtype == torch.bfloat16
+    assert rel_l2(out_b.float(), ref) < 4e-3
+
+
+def test_gemm_bf16_epilogues(dx):
+    ops, _ = dx
+    g = torch.Generator().manual_seed(9)
+    M, N, K = 402, 256, 128
+    A, B = torch.randn(M, K, generator=g).bfloat16(), (0.1 * torch.randn(N, K, generator=g)).bfloat16()
+    bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    pre = A.double() @ B.double().t() + bias.double()
+    aux = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    act = ops.gemm(A.to(DEV), B.to(DEV), bias=bias.to(DEV), gelu=True, aux=aux)
+    assert rel_l2(aux.float(), pre) < 4e-3
+    assert rel_l2(act.float(), 0.5 * pre * (1 + torch.erf(pre / math.sqrt(2)))) < 5e-3
+    y = ops.gemm(A.to(DEV), B.to(DEV), bias=bias.to(DEV), residual=res.to(DEV), out_dtype=torch.float32)
+    close(y, pre + res.double(), 1e-5, 1e-4, "bias+residual fp32 out")
+    auxf = aux.float().double().cpu()
+    dg = 0.5 * (1 + torch.erf(auxf / math.sqrt(2))) + auxf * torch.exp(-0.5 * auxf * auxf) / math.sqrt(2 * math.pi)
+    d = ops.gemm(A.to(DEV), B.to(DEV), dgelu=True, aux=aux)
+    assert rel_l2(d.float(), (A.double() @ B.double().t()) * dg) < 5e-3
+
+
+def test_colsum(dx):
+    ops, _ = dx
+    x = torch.randn(1003, 130)
+    close(ops.colsum(x.to(DEV)), x.double().sum(0), 1e-5, 1e-4, "colsum f32")
+    xb = x.bfloat16()
+    close(ops.colsum(xb.to(DEV)), xb.double().sum(0), 1e-5, 1e-4, "colsum bf16")
+
+
+# ------------------------------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("rows,dim", [(7, 64), (804, 384), (33, 1024), (5, 50)])
+def test_layernorm(dx, rows, dim):
+    ops, _ = dx
+    from oracle import kernels_np as K
+    rng = np.random.default_rng(rows + dim)
+    x, w, b, dy = rng.normal(size=(rows, dim)) * 2 + 0.5, rng.normal(size=dim), rng.normal(size=dim), rng.normal(size=(rows, dim))
+    y_ref, mu, rstd = K.layernorm_fwd(x, w, b)
+    dx_ref, dw_ref, db_ref = K.layernorm_bwd(dy, x, w, mu, rstd)
+    X, W, Bb, DY = [torch.tensor(a, dtype=torch.float32, device=DEV) for a in (x, w, b, dy)]
+    y, mean, rs = ops.layernorm_fwd(X, W, Bb, torch.float32)
+    close(y, y_ref, 1e-5, 1e-5, "ln y")
+    yb, _, _ = ops.layernorm_fwd(X, W, Bb, torch.bfloat16)
+    assert rel_l2(yb.float(), y_ref) < 4e-3
+    base = torch.ones(rows, dim, device=DEV)
+    dxo, dw, db, lowp = ops.layernorm_bwd(DY, X, W, mean, rs, dx=base.clone(), accumulate=True, want_lowp=True)
+    close(dxo, dx_ref + 1.0, 2e-5, 2e-5, "ln dx (accumulate)")
+    close(dw, dw_ref, 2e-5, 1e-4, "ln dw")
+    close(db, db_ref, 2e-5, 1e-4, "ln db")
+    assert rel_l2(lowp.float(), dx_ref + 1.0) < 4e-3
+    dxb, dwb, _, _ = ops.layernorm_bwd(DY.bfloat16(), X, W, mean, rs)
+    assert rel_l2(dxb, dx_ref) < 6e-3 and rel_l2(dwb, dw_ref) < 6e-3
+
+
+# ------------------------------------------------------------------------------------------ modules vs golden
+def _load(mod, sd):
+    mod.load_state_dict({k: v for k, v in sd.items()})
+    return mod.to(DEV)
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_attention_module_golden(dx, mode):
+    ops, arch = dx
+    g = load_golden("ops_attention.npz")
+    m = _load(arch.Attention(128, num_heads=int(g["heads"])), sub(g, "w"))
+    x = t(g["x"]).to(DEV).requires_grad_(True)
+    dt = torch.float32 if mode == "fp32" else torch.bfloat16
+    with ops.compute_dtype(dt):
+        y = m(x)
+        y.float().backward(t(g["dy"]).to(DEV))
+    if mode == "fp32":
+        close(y, g["y"], 1e-4, 1e-5, "attn y")
+        close(x.grad, g["dx"], 1e-4, 1e-5, "attn dx")
+        for k, v in sub(g, "g").items():
+            close(dict(m.named_parameters())[k].grad, v, 2e-4, 1e-5, f"attn d{k}")
+    else:
+        assert rel_l2(y.float(), g["y"]) < 1.5e-2
+        assert rel_l2(x.grad, g["dx"]) < 2.5e-2
+        for k, v in sub(g, "g").items():
+            assert rel_l2(dict(m.named_parameters())[k].grad, v) < 2.5e-2, k
+
+
+@pytest.mark.parametrize("B,N,h,d", [(2, 201, 6, 64), (1, 19, 2, 32), (3, 64, 1, 64), (1, 261, 2, 64), (2, 7, 2, 16)])
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_attention_core_vs_np(dx, B, N, h, d, mode):
+    ops, _ = dx
+    from oracle import kernels_np as K
+    rng = np.random.default_rng(N * 7 + d)
+    qkv = rng.normal(size=(B, N, 3 * h * d)).astype(np.float32)
+    do = rng.normal(size=(B, N, h * d)).astype(np.float32)
+    dt = torch.float32 if mode == "fp32" else torch.bfloat16
+    Q = torch.tensor(qkv, device=DEV).to(dt)
+    DO = torch.tensor(do, device=DEV).to(dt)
+    qkv_r, do_r = Q.float().cpu().double().numpy(), DO.float().cpu().double().numpy()
+    o_ref, lse_ref = K.attention_core_fwd(qkv_r, h)
+    o, lse = ops.attention_fwd(Q, h)
+    dq_ref = K.attention_core_bwd(do_r, qkv_r, o_ref, lse_ref, h)
+    dqkv = ops.attention_bwd(DO, Q, o, lse, h)
+    if mode == "fp32":
+        close(o, o_ref, 2e-5, 2e-5, "o")
+        close(lse, lse_ref, 2e-5, 2e-5, "lse")
+        close(dqkv, dq_ref, 1e-4, 1e-4, "dqkv")
+    else:
+        assert rel_l2(o.float(), o_ref) < 8e-3
+        close(lse, lse_ref, 1e-3, 1e-2, "lse")
+        assert rel_l2(dqkv.float(), dq_ref) < 2e-2
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_mlp_module_golden(dx, mode):
+    ops, arch = dx
+    g = load_golden("ops_mlp.npz")
+    m = _load(arch.Mlp(64, 4.0), sub(g, "w"))
+    x = t(g["x"]).to(DEV).requires_grad_(True)
+    dt = torch.float32 if mode == "fp32" else torch.bfloat16
+    with ops.compute_dtype(dt):
+        y = m(x)
+        y.float().backward(t(g["dy"]).to(DEV))
+    P = dict(m.named_parameters())
+    if mode == "fp32":
+        close(y, g["y"], 1e-4, 1e-5, "mlp y")
+        close(x.grad, g["dx"], 1e-4, 1e-5, "mlp dx")
+        for k, v in sub(g, "g").items():
+            close(P[k].grad, v, 2e-4, 1e-5, f"mlp d{k}")
+    else:
+        assert rel_l2(y.float(), g["y"]) < 1.5e-2
+        assert rel_l2(x.grad, g["dx"]) < 2e-2
+        for k, v in sub(g, "g").items():
+            assert rel_l2(P[k].grad, v) < 2e-2, k
+
+
+def test_scale_embedding_golden(dx):
+    ops, arch = dx
+    g = load_golden("ops_scale_embed.npz")
+    m = _load(arch.ScaleEmbedding(64), sub(g, "w"))
+    sp = t(g["spacing"]).to(DEV).requires_grad_(True)
+    y = m(sp)
+    assert y.shape == (5, 1, 64)
+    close(y, g["y"], 1e-4, 1e-5, "scale y")
+    y.backward(t(g["dy"]).to(DEV))
+    close(sp.grad, g["dspacing"], 5e-4, 1e-5, "dspacing")
+    P = dict(m.named_parameters())
+    for k, v in sub(g, "g").items():
+        close(P[k].grad, v, 5e-4, 1e-5, f"scale d{k}")
+
+
+def test_scale_embedding_zero_init_is_noop(dx):
+    """reference tests/test_scale_embedding.py:51-62: a fresh module outputs ~0."""
+    _, arch = dx
+    m = arch.ScaleEmbedding(64).to(DEV)
+    y = m(torch.tensor([[0.5, 0.5, 1.0], [1.5, 1.5, 5.0]], device=DEV))
+    assert y.abs().max().item() < 1e-3
+
+
+def test_dino_loss_golden(dx):
+    ops, _ = dx
+    g = load_golden("dino_loss.npz")
+    s = t(g["s"]).to(DEV).requires_grad_(True)
+    c = t(g["center0"]).to(DEV).clone()
+    l1 = ops.DinoCEFn.apply(s, t(g["t"]).to(DEV), c, 0.1, 0.04)
+    close(l1, g["loss1"], 1e-5, 1e-6, "dino loss1")
+    l1.backward()
+    close(s.grad, g["ds1"], 1e-4, 1e-8, "dino ds")
+    ops.center_ema_(c.view(-1), ops.colmean(t(g["t"]).to(DEV)), 0.9)
+    close(c, g["center1"], 1e-5, 1e-7, "center1")
+    l2, _ = ops.dino_ce(s.detach(), t(g["t2"]).to(DEV), c, 0.1, 0.04, False)
+    close(l2.reshape(()), g["loss2"], 1e-5, 1e-6, "dino loss2")
+
+
+def test_dino_loss_survey_known_answer(dx):
+    ops, _ = dx
+    from oracle.dinox_oracle import det
+    S, T = det(8, 128, f=0.37).to(DEV), (2 * det(8, 128, f=0.91, ph=0.5)).to(DEV)
+    c = torch.zeros(1, 128, device=DEV)
+    l, _ = ops.dino_ce(S, T, c, 0.1, 0.04, False)
+    assert float(l) == pytest.approx(12.77463341, rel=1e-5)
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_gram_loss_golden(dx, mode):
+    ops, _ = dx
+    g = load_golden("gram_loss.npz")
+    sf = t(g["sf"]).to(DEV).requires_grad_(True)
+    dt = torch.float32 if mode == "fp32" else torch.bfloat16
+    with ops.compute_dtype(dt):
+        l = ops.GramLossFn.apply(sf, t(g["tf"]).to(DEV))
+        l.backward()
+    ref = torch.as_tensor(g["dsf"]).clone()
+    got = sf.grad.cpu().clone()
+    if mode == "fp32":
+        close(l, g["loss"], 1e-5, 1e-7, "gram loss")
+        # the zero-norm token's gradient is ~1e12-scaled noise in the reference too: compare it loosely
+        assert rel_l2(got[1, 5], ref[1, 5]) < 1e-3
+        got[1, 5] = 0; ref[1, 5] = 0
+        close(got, ref, 2e-4, 1e-8, "gram dsf")
+    else:
+        assert float(l) == pytest.approx(float(g["loss"]), rel=2e-2)
+        got[1, 5] = 0; ref[1, 5] = 0
+        assert rel_l2(got, ref) < 3e-2
+
+
+# ------------------------------------------------------------------------------------------ whole model
+def _cfg(arr):
+    img, patch, dim, depth, heads, regs, sa, out = [int(v) for v in arr]
+    return dict(img_size=img, patch=patch, dim=dim, depth=depth, heads=heads, num_registers=regs, scale_aware=bool(sa)), out
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_vit_tiny_golden(dx, mode):
+    ops, arch = dx
+    g = load_golden("vit_tiny.npz")
+    cfg, out_dim = _cfg(g["cfg"])
+    student = _load(arch.DinoStudentTeacher(arch.PatchViT(**cfg), out_dim), sub(g, "student"))
+    teacher = _load(arch.DinoStudentTeacher(arch.PatchViT(**cfg), out_dim), sub(g, "teacher"))
+    x, sp = t(g["x"]).to(DEV), t(g["spacing"]).to(DEV)
+    center = t(g["center"]).to(DEV).clone()
+    dt = torch.float32 if mode == "fp32" else torch.bfloat16
+    with ops.compute_dtype(dt):
+        s_feats = student.backbone(x, spacing=sp)
+        with torch.no_grad():
+            t_feats = teacher.backbone(x, spacing=sp)
+            t_out = teacher.head(t_feats[:, 0])
+            nosp = student.backbone(x, spacing=None)
+        s_out = student.head(s_feats[:, 0])
+        l_dino = ops.DinoCEFn.apply(s_out, t_out, center, 0.1, 0.04)
+        l_gram = ops.GramLossFn.apply(s_feats, t_feats)
+        (l_dino + l_gram).backward()
+    assert s_feats.dtype == torch.float32 and s_feats.shape == (4, 21, 64)
+    P = dict(student.named_parameters())
+    if mode == "fp32":
+        close(s_feats, g["s_feats"], 1e-4, 1e-5, "s_feats")
+        close(t_feats, g["t_feats"], 1e-4, 1e-5, "t_feats")
+        close(nosp, g["feats_nospacing"], 1e-4, 1e-5, "feats_nospacing")
+        close(s_out, g["s_out"], 1e-4, 1e-5, "s_out")
+        close(l_dino, g["loss_dino"], 1e-4, 0, "loss_dino")
+        close(l_gram, g["loss_gram"], 1e-4, 0, "loss_gram")
+        for n in [str(s) for s in g["param_order"]]:
+            close(P[n].grad, g[f"grad/{n}"], 1e-3, 2e-7, f"grad {n}")      # the north-star 1e-3 gate
+    else:
+        assert rel_l2(s_feats, g["s_feats"]) < 2e-2
+        assert rel_l2(s_out, g["s_out"]) < 3e-2
+        assert float(l_dino) == pytest.approx(float(g["loss_dino"]), rel=3e-2)
+        assert float(l_gram) == pytest.approx(float(g["loss_gram"]), rel=5e-2)
+        bad = [n for n in [str(s) for s in g["param_order"]]
+               if rel_l2(P[n].grad, g[f"grad/{n}"]) > 0.08 and np.abs(g[f"grad/{n}"]).max() > 1e-6]
+        assert not bad, bad
+
+
+def test_vit_plain_golden_no_registers(dx):
+    ops, arch = dx
+    g = load_golden("vit_plain.npz")
+    m = arch.PatchViT(img_size=28, patch=14, dim=32, depth=1, heads=2, mlp_ratio=2.0, num_registers=0, scale_aware=False)
+    assert not hasattr(m, "scale_embed") and not hasattr(m, "registers")
+    m = _load(m, sub(g, "w")).eval()
+    with torch.no_grad():
+        y = m(t(g["x"]).to(DEV))
+    assert y.shape == (3, 5, 32)
+    close(y, g["y"], 1e-4, 1e-5, "vit_plain")
+
+
+def test_backward_populates_every_scale_embed_grad(dx):
+    """reference tests/test_scale_embedding.py:331-348."""
+    _, arch = dx
+    torch.manual_seed(0)
+    m = arch.DinoStudentTeacher(arch.PatchViT(56, 14, 64, 2, 2, scale_aware=True), 128).to(DEV)
+    torch.nn.init.xavier_uniform_(m.backbone.scale_embed.mlp[2].weight)
+    out = m(torch.randn(2, 3, 56, 56, device=DEV), spacing=torch.tensor([[0.5, 0.5, 1.0], [1.5, 1.5, 5.0]], device=DEV))
+    assert out.shape == (2, 128)
+    out.pow(2).mean().backward()
+    for n, p in m.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), n
+        if "scale_embed" in n:
+            assert p.grad.abs().sum() > 0, n
+
+
+# ------------------------------------------------------------------------------------------ optimiser tail + step
+def test_adamw_ema_vs_np(dx):
+    ops, _ = dx
+    from oracle import kernels_np as K
+    rng = np.random.default_rng(3)
+    n = 10007
+    p, g_, m, v, pt = rng.normal(size=n), rng.normal(size=n), rng.normal(size=n) * 0.1, np.abs(rng.normal(size=n)) * 0.01, rng.normal(size=n)
+    pn, mn, vn, ptn, gsq = K.adamw_ema(p, 0.5 * g_, m, v, pt, 3, 2e-3, 0.04, 0.9, 0.999, 1e-8, 0.996)
+    n_pad = (n + 3) // 4 * 4
+    def dev(a):
+        z = torch.zeros(n_pad, dtype=torch.float32, device=DEV)
+        z[:n] = torch.tensor(a, dtype=torch.float32)
+        return z
+    P, G, M, V, T = dev(p), dev(g_), dev(m), dev(v), dev(pt)
+    out = ops.adamw_ema_(P, G, M, V, T, lr=2e-3, weight_decay=0.04, beta1=0.9, beta2=0.999, eps=1e-8, step_t=3, ema=0.996, grad_scale=0.5)
+    close(P[:n], pn, 1e-5, 1e-6, "p"); close(M[:n], mn, 1e-5, 1e-6, "m"); close(V[:n], vn, 1e-5, 1e-7, "v"); close(T[:n], ptn, 1e-5, 1e-6, "teacher")
+    assert float(out) == pytest.approx(gsq, rel=1e-5)
+    assert float(ops.sumsq(G)) == pytest.approx(float((g_ * g_).sum()), rel=1e-5)
+
+
+def test_three_training_steps_golden(dx):
+    """The engine's step() against 3 consecutive steps of the reference loop (fp32 parity mode)."""
+    ops, arch = dx
+    from dinox.engine import StepHyperParams, TrainEngine
+    g = load_golden("step_tiny.npz")
+    cfg, out_dim = _cfg(g["cfg"])
+    lr, min_lr, warm, max_steps, wd, ema, ts, tt, cm, gw = [float(v) for v in g["hp"]]
+    hp = StepHyperParams(lr=lr, min_lr=min_lr, warmup_steps=int(warm), max_steps=int(max_steps), weight_decay=wd, ema=ema,
+                         student_temp=ts, teacher_temp=tt, center_momentum=cm, gram_weight=gw)
+    student = _load(arch.DinoStudentTeacher(arch.PatchViT(**cfg), out_dim), sub(g, "init"))
+    teacher = _load(arch.DinoStudentTeacher(arch.PatchViT(**cfg), out_dim), sub(g, "init"))
+    eng = TrainEngine(student, teacher, out_dim, hp)
+    for step in range(3):
+        eng.step(t(g[f"batch{step}"]).to(DEV), t(g[f"spacing{step}"]).to(DEV))
+        r = eng.scalars()
+        assert r["loss"] == pytest.approx(float(g["losses"][step]), rel=1e-3)
+        assert r["dino"] == pytest.approx(float(g["dinos"][step]), rel=1e-3)
+        assert r["gram"] == pytest.approx(float(g["grams"][step]), rel=1e-3, abs=1e-9)
+        assert r["grad_norm"] == pytest.approx(float(g["grad_norms"][step]), rel=1e-3)
+        assert r["lr"] == pytest.approx(float(g["lrs"][step]), rel=1e-12)
+    # Adam amplifies round-off on numerically-zero gradients to +-lr (see tests/test_oracle_golden.py);
+    # compare with an lr-scaled absolute floor: 3 steps, lr <= 1e-3.
+    sd = student.state_dict()
+    worst = 0.0
+    for k, v in sub(g, "student3").items():
+        d = (sd[k].cpu().double() - v.double()).abs().max().item()
+        worst = max(worst, d)
+        assert d <= 6.5e-3, (k, d)
+    frac_tight = np.mean([float(((sd[k].cpu().double() - v.double()).abs() <= 1e-3 * v.double().abs().max() + 1e-5).double().mean())
+                          for k, v in sub(g, "student3").items()])
+    assert frac_tight > 0.97, frac_tight
+    close(eng.center, g["center3"], 1e-3, 1e-6, "center3")
+    tsd = teacher.state_dict()
+    for k, v in sub(g, "teacher3").items():
+        assert (tsd[k].cpu().double() - v.double()).abs().max().item() <= 2e-3, k
+
+
+def test_cpu_tensors_fail_loudly(dx):
+    _, arch = dx
+    m = arch.PatchViT(28, 14, 32, 1, 2)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.randn(1, 3, 28, 28))

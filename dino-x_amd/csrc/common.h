@@ -21,7 +21,7 @@ int check_launch(const char* what);  // hipGetLastError -> 0 or positive hipErro
   } while (0)
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
-static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+__host__ __device__ static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // ---------------------------------------------------------------- device: types
 typedef uint16_t bf16_t;  // raw bf16 bits

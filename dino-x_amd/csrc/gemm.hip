@@ -27,6 +27,25 @@ __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ x,
 
 using namespace dinox;
 
+static void to_params(const dinox_gemm_args* a, GemmParams& p) {
+  p.A = a->A; p.B = a->B; p.C = a->C;
+  p.M = a->M; p.N = a->N; p.K = a->K;
+  p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc;
+  p.batch = a->batch; p.strideA = a->strideA; p.strideB = a->strideB; p.strideC = a->strideC;
+  p.transA = a->transA ? 1 : 0; p.transB = a->transB ? 1 : 0;
+  p.in_dtype = a->in_dtype; p.out_dtype = a->out_dtype; p.epilogue = a->epilogue;
+  p.alpha = a->alpha;
+  p.bias = a->bias; p.residual = a->residual; p.ldr = a->ldr; p.aux = a->aux; p.ldaux = a->ldaux;
+}
+
+extern "C" const char* dinox_gemm_kernel_name(const dinox_gemm_args* a) {
+  if (!a) return "";
+  GemmParams p;
+  to_params(a, p);
+  const char* v = gemm_bf16_variant(p);
+  return v ? v : "gemm_f32";
+}
+
 extern "C" int dinox_gemm(const dinox_gemm_args* a, void* stream) {
   DX_REQUIRE(a, DINOX_EINVAL, "gemm: null args");
   DX_REQUIRE(a->A && a->B && a->C, DINOX_EINVAL, "gemm: null operand");
@@ -43,16 +62,8 @@ extern "C" int dinox_gemm(const dinox_gemm_args* a, void* stream) {
   DX_REQUIRE(!(e & DINOX_EPI_GELU) || !a->aux || a->ldaux >= a->N, DINOX_EINVAL, "gemm: GELU aux ldaux too small");
   DX_REQUIRE(!((e & DINOX_EPI_GELU) && (e & DINOX_EPI_DGELU)), DINOX_EINVAL, "gemm: GELU and DGELU are exclusive");
   DX_REQUIRE(!(e & DINOX_EPI_ACCUM) || a->out_dtype == DINOX_F32, DINOX_EINVAL, "gemm: ACCUM needs fp32 C");
-  DX_REQUIRE(a->batch == 1 || !(e & (DINOX_EPI_RESIDUAL | DINOX_EPI_GELU | DINOX_EPI_DGELU)) || true, DINOX_EINVAL, "gemm");
   GemmParams p;
-  p.A = a->A; p.B = a->B; p.C = a->C;
-  p.M = a->M; p.N = a->N; p.K = a->K;
-  p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc;
-  p.batch = a->batch; p.strideA = a->strideA; p.strideB = a->strideB; p.strideC = a->strideC;
-  p.transA = a->transA ? 1 : 0; p.transB = a->transB ? 1 : 0;
-  p.in_dtype = a->in_dtype; p.out_dtype = a->out_dtype; p.epilogue = e;
-  p.alpha = a->alpha;
-  p.bias = a->bias; p.residual = a->residual; p.ldr = a->ldr; p.aux = a->aux; p.ldaux = a->ldaux;
+  to_params(a, p);
   hipStream_t st = as_stream(stream);
   if (p.in_dtype == DINOX_BF16) {
     const int rc = launch_gemm_bf16(p, st);

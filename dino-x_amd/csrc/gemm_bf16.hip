@@ -1,6 +1,324 @@
-// gemm_bf16.hip -- placeholder until the MFMA bf16 kernels land (next commit).
+// gemm_bf16.hip -- bf16 MFMA GEMMs (v_mfma_f32_32x32x16_bf16, fp32 accumulate) for gfx950.
+//
+//   gemm_bf16_nt : C[M,N] = A[M,K] . B[N,K]^T   both operands K-contiguous (forward products and, with the
+//                  pre-transposed bf16 weight copies, every dX product).  Fragments by ds_read_b128 from an
+//                  XOR-swizzled [rows][64] bf16 LDS image (chunk ^= (row>>1)&7: conflict-free for the
+//                  ds_read_b128 lane groups of gfx950, MI355X_MICROARCH.md LDS table).
+//   gemm_bf16_tn : C[M,N] = A[K,M]^T . B[K,N]   both operands stored reduction-major (dW = dY^T X with the
+//                  token dimension as K).  Tiles are staged as they lie in memory ([k][m], 256-B rows) and
+//                  the MFMA operands are fetched with the gfx950 transposing LDS read ds_read_b64_tr_b16;
+//                  64-B granules are XOR-swizzled with (k&3) so the 4 k-rows of a read hit distinct banks.
+//                  K (= tokens, ~1e5) is split across workgroups; partial tiles meet through fp32 atomics.
+//
+// Tile 128x128x64, 256 threads = 4 waves (2x2), each wave 64x64 = 2x2 MFMA tiles, 64 accumulator VGPRs.
+// LDS: 2 stages x (16 KiB A + 16 KiB B) = 64 KiB -> 2 workgroups per CU.  Global loads are issued one
+// K-step ahead into registers and written to the other LDS stage after the MFMAs (one barrier per step).
+// Workgroup ids are remapped so that each XCD walks a contiguous run of tiles: the N-tiles that share an
+// A row-panel hit that XCD's private L2 (cdna_hip_programming.md T1, bijective form).
 #include "common.h"
 #include "gemm_common.h"
+
 namespace dinox {
-int launch_gemm_bf16(const GemmParams&, hipStream_t) { return DINOX_EUNSUPPORTED; }
+
+constexpr int GB_BM = 128, GB_BN = 128, GB_BK = 64, GB_THREADS = 256;
+constexpr int GB_TILE_BYTES = 128 * 64 * 2;  // 16 KiB per operand tile (NT: [128][64]; TN: [64][128])
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ __forceinline__ uint4 ldg16(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+
+// XCD-aware bijective remap of a 1-D workgroup id (8 XCDs, round-robin dispatch).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// ------------------------------------------------------------------------------------------ NT
+struct NtStage {
+  uint4 a[4], b[4];
+};
+
+// thread t loads chunk c = t&7 (8 bf16 = 16 B along K) of rows (t>>3) + 32*i
+__device__ __forceinline__ void nt_load(NtStage& s, const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, int64_t lda,
+                                        int64_t ldb, int64_t m0, int64_t n0, int64_t k0, int64_t M, int64_t N, int64_t K) {
+  const int c = threadIdx.x & 7, r0 = threadIdx.x >> 3;
+  const int64_t k = k0 + c * 8;
+  const bool kin = k < K;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + 32 * i;
+    int64_t gm = m0 + r, gn = n0 + r;
+    gm = gm < M ? gm : M - 1;  // clamp: rows past the edge are computed but never stored
+    gn = gn < N ? gn : N - 1;
+    s.a[i] = kin ? ldg16(A + gm * lda + k) : make_uint4(0, 0, 0, 0);
+    s.b[i] = kin ? ldg16(B + gn * ldb + k) : make_uint4(0, 0, 0, 0);
+  }
+}
+
+__device__ __forceinline__ void nt_store(const NtStage& s, char* __restrict__ sa, char* __restrict__ sb) {
+  const int c = threadIdx.x & 7, r0 = threadIdx.x >> 3;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + 32 * i;
+    const int off = r * 128 + ((c ^ ((r >> 1) & 7)) << 4);
+    *reinterpret_cast<uint4*>(sa + off) = s.a[i];
+    *reinterpret_cast<uint4*>(sb + off) = s.b[i];
+  }
+}
+
+template <int OUT_DT>
+__global__ __launch_bounds__(GB_THREADS, 2) void gemm_bf16_nt(GemmParams p, int tiles_m, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wr = wv >> 1, wc = wv & 1;
+  const int ntile = tiles_m * tiles_n;
+  const int tile = xcd_remap(blockIdx.x, ntile);
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  const int64_t m0 = (int64_t)tm * GB_BM, n0 = (int64_t)tn * GB_BN;
+  const int64_t bz = blockIdx.y;
+  const bf16_t* A = (const bf16_t*)p.A + bz * p.strideA;
+  const bf16_t* B = (const bf16_t*)p.B + bz * p.strideB;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nk = (int)ceil_div(p.K, GB_BK);
+  NtStage st;
+  nt_load(st, A, B, p.lda, p.ldb, m0, n0, 0, p.M, p.N, p.K);
+  nt_store(st, smem, smem + GB_TILE_BYTES);
+  __syncthreads();
+
+  const int frow = lane & 31, fh = lane >> 5;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    char* sa = smem + cur * 2 * GB_TILE_BYTES;
+    char* sb = sa + GB_TILE_BYTES;
+    if (kt + 1 < nk) nt_load(st, A, B, p.lda, p.ldb, m0, n0, (int64_t)(kt + 1) * GB_BK, p.M, p.N, p.K);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 af[2], bfr[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int ra = wr * 64 + i * 32 + frow;
+        const int rb = wc * 64 + i * 32 + frow;
+        const int kc = 2 * ks + fh;
+        af[i] = *reinterpret_cast<const bf16x8*>(sa + ra * 128 + ((kc ^ ((ra >> 1) & 7)) << 4));
+        bfr[i] = *reinterpret_cast<const bf16x8*>(sb + rb * 128 + ((kc ^ ((rb >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+      char* na = smem + (cur ^ 1) * 2 * GB_TILE_BYTES;
+      nt_store(st, na, na + GB_TILE_BYTES);
+    }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int64_t n = n0 + wc * 64 + j * 32 + (lane & 31);
+    if (n >= p.N) continue;
+    const float bias = (p.epilogue & DINOX_EPI_BIAS) ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int64_t m = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (m < p.M) epilogue_store<OUT_DT>(p, bz, m, n, acc[i][j][e], bias);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ TN
+struct TnStage {
+  uint4 a[4], b[4];
+};
+
+// tile rows are K (64 rows of 256 B = 128 bf16 along M or N); thread t: chunk c = t&15, rows (t>>4) + 16*i
+__device__ __forceinline__ void tn_load(TnStage& s, const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, int64_t lda,
+                                        int64_t ldb, int64_t m0, int64_t n0, int64_t k0, int64_t kend, int64_t M, int64_t N) {
+  const int c = threadIdx.x & 15, r0 = threadIdx.x >> 4;
+  const int64_t m = m0 + c * 8, n = n0 + c * 8;
+  const bool min_ = m < M, nin = n < N;  // M, N are multiples of 8: a chunk is wholly in or out
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t k = k0 + r0 + 16 * i;
+    const bool kin = k < kend;
+    s.a[i] = (kin && min_) ? ldg16(A + k * lda + m) : make_uint4(0, 0, 0, 0);
+    s.b[i] = (kin && nin) ? ldg16(B + k * ldb + n) : make_uint4(0, 0, 0, 0);
+  }
+}
+
+// 16-B chunk c of k-row r goes to granule ((c>>2) ^ (r&3)), slot (c&3)
+__device__ __forceinline__ void tn_store(const TnStage& s, char* __restrict__ sa, char* __restrict__ sb) {
+  const int c = threadIdx.x & 15, r0 = threadIdx.x >> 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + 16 * i;
+    const int off = r * 256 + ((((c >> 2) ^ (r & 3)) << 6) | ((c & 3) << 4));
+    *reinterpret_cast<uint4*>(sa + off) = s.a[i];
+    *reinterpret_cast<uint4*>(sb + off) = s.b[i];
+  }
+}
+
+// Transposed fragment for mfma_32x32x16: lane (col = l&31, h = l>>5) gets tile[k = kbase + 8h + j][col0 + col], j<8.
+__device__ __forceinline__ bf16x8 tn_frag(const char* __restrict__ tile, int kbase, int col0, int lane) {
+  const int i = lane & 15, g = lane >> 4;
+  const int q = i >> 2, pp = i & 3;
+  const int colb = (col0 + 16 * (g & 1) + 4 * pp) * 2;  // byte offset of this lane's 4-element piece in its k-row
+  const int k0 = kbase + 8 * (g >> 1) + q;
+  const int k1 = k0 + 4;
+  const int o0 = k0 * 256 + ((((colb >> 6) ^ (k0 & 3)) << 6) | (colb & 63));
+  const int o1 = k1 * 256 + ((((colb >> 6) ^ (k1 & 3)) << 6) | (colb & 63));
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + o0));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + o1));
+  s16x8 v;
+  v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+  v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int OUT_DT>
+__global__ __launch_bounds__(GB_THREADS, 2) void gemm_bf16_tn(GemmParams p, int tiles_m, int tiles_n, int splits,
+                                                              int64_t k_per_split) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wr = wv >> 1, wc = wv & 1;
+  const int ntile = tiles_m * tiles_n;
+  const int tile = xcd_remap(blockIdx.x, ntile);
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  const int64_t m0 = (int64_t)tm * GB_BM, n0 = (int64_t)tn * GB_BN;
+  const int64_t bz = blockIdx.y / splits;
+  const int split = blockIdx.y % splits;
+  const int64_t kbeg = (int64_t)split * k_per_split;
+  int64_t kend = kbeg + k_per_split;
+  if (kend > p.K) kend = p.K;
+  const bf16_t* A = (const bf16_t*)p.A + bz * p.strideA;
+  const bf16_t* B = (const bf16_t*)p.B + bz * p.strideB;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nk = kend > kbeg ? (int)ceil_div(kend - kbeg, GB_BK) : 0;
+  TnStage st;
+  if (nk > 0) {
+    tn_load(st, A, B, p.lda, p.ldb, m0, n0, kbeg, kend, p.M, p.N);
+    tn_store(st, smem, smem + GB_TILE_BYTES);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    const char* sa = smem + cur * 2 * GB_TILE_BYTES;
+    const char* sb = sa + GB_TILE_BYTES;
+    if (kt + 1 < nk) tn_load(st, A, B, p.lda, p.ldb, m0, n0, kbeg + (int64_t)(kt + 1) * GB_BK, kend, p.M, p.N);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 af[2], bfr[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[i] = tn_frag(sa, ks * 16, wr * 64 + i * 32, lane);
+        bfr[i] = tn_frag(sb, ks * 16, wc * 64 + i * 32, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+      char* na = smem + (cur ^ 1) * 2 * GB_TILE_BYTES;
+      tn_store(st, na, na + GB_TILE_BYTES);
+    }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int64_t n = n0 + wc * 64 + j * 32 + (lane & 31);
+    if (n >= p.N) continue;
+    const float bias = (p.epilogue & DINOX_EPI_BIAS) ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int64_t m = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (m >= p.M) continue;
+        if (splits > 1)
+          atomicAdd((float*)p.C + bz * p.strideC + m * p.ldc + n, acc[i][j][e] * p.alpha);  // C zeroed / accumulating
+        else
+          epilogue_store<OUT_DT>(p, bz, m, n, acc[i][j][e], bias);
+      }
+    }
+  }
+}
+
+static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+const char* gemm_bf16_variant(const GemmParams& p) {
+  if (p.in_dtype != DINOX_BF16) return nullptr;
+  if (!aligned16(p.A) || !aligned16(p.B) || (p.lda & 7) || (p.ldb & 7) || (p.strideA & 7) || (p.strideB & 7)) return nullptr;
+  if (p.transA == 0 && p.transB == 0 && (p.K & 7) == 0) return "gemm_bf16_nt";
+  if (p.transA == 1 && p.transB == 1 && (p.M & 7) == 0 && (p.N & 7) == 0) return "gemm_bf16_tn";
+  return nullptr;
+}
+
+int launch_gemm_bf16(const GemmParams& p, hipStream_t st) {
+  const char* v = gemm_bf16_variant(p);
+  if (!v) return DINOX_EUNSUPPORTED;
+  const int tiles_m = (int)ceil_div(p.M, GB_BM), tiles_n = (int)ceil_div(p.N, GB_BN);
+  const int64_t ntile = (int64_t)tiles_m * tiles_n;
+  if (ntile > 0x7fffffff || p.batch > 65535) return DINOX_EUNSUPPORTED;
+  const size_t lds = 4 * GB_TILE_BYTES;
+  if (v[10] == 'n') {  // "gemm_bf16_nt"
+    dim3 grid((unsigned)ntile, (unsigned)p.batch);
+    if (p.out_dtype == DINOX_F32)
+      hipLaunchKernelGGL((gemm_bf16_nt<DINOX_F32>), grid, dim3(GB_THREADS), lds, st, p, tiles_m, tiles_n);
+    else
+      hipLaunchKernelGGL((gemm_bf16_nt<DINOX_BF16>), grid, dim3(GB_THREADS), lds, st, p, tiles_m, tiles_n);
+    return check_launch("gemm_bf16_nt");
+  }
+  // TN: split K so that the grid has ~2 workgroups per CU; split results meet through fp32 atomics.
+  int splits = 1;
+  const bool plain = (p.epilogue & ~DINOX_EPI_ACCUM) == 0 && p.out_dtype == DINOX_F32;
+  if (plain) {
+    const int64_t want = 512, have = ntile * p.batch;
+    splits = (int)ceil_div(want, have);
+    const int64_t max_splits = ceil_div(p.K, 4 * GB_BK);  // at least 4 K-steps per workgroup
+    if (splits > max_splits) splits = (int)max_splits;
+    if (splits < 1) splits = 1;
+  }
+  int64_t kps = ceil_div(ceil_div(p.K, splits), GB_BK) * GB_BK;
+  splits = (int)ceil_div(p.K, kps);
+  if ((int64_t)splits * p.batch > 65535) return DINOX_EUNSUPPORTED;
+  if (splits > 1 && !(p.epilogue & DINOX_EPI_ACCUM)) {
+    // zero C (rows may be strided by ldc; batch by strideC): contiguous case only, else fall back to 1 split
+    if (p.ldc == p.N && (p.batch == 1 || p.strideC == p.M * p.N)) {
+      hipError_t e = hipMemsetAsync(p.C, 0, (size_t)p.batch * p.M * p.N * sizeof(float), st);
+      if (e != hipSuccess) return fail((int)e, "gemm_bf16_tn: memset: %s", hipGetErrorString(e));
+    } else {
+      splits = 1;
+      kps = ceil_div(p.K, GB_BK) * GB_BK;
+    }
+  }
+  dim3 grid((unsigned)ntile, (unsigned)(p.batch * splits));
+  if (p.out_dtype == DINOX_F32)
+    hipLaunchKernelGGL((gemm_bf16_tn<DINOX_F32>), grid, dim3(GB_THREADS), lds, st, p, tiles_m, tiles_n, splits, kps);
+  else
+    hipLaunchKernelGGL((gemm_bf16_tn<DINOX_BF16>), grid, dim3(GB_THREADS), lds, st, p, tiles_m, tiles_n, splits, kps);
+  return check_launch("gemm_bf16_tn");
+}
+
 }  // namespace dinox

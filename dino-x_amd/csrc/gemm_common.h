@@ -38,6 +38,7 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int64_t bz, 
 }
 
 int launch_gemm_f32(const GemmParams& p, hipStream_t st);
+const char* gemm_bf16_variant(const GemmParams& p);  // kernel the bf16 dispatcher would use, or nullptr
 int launch_gemm_bf16(const GemmParams& p, hipStream_t st);  // returns DINOX_EUNSUPPORTED when it cannot take the shape
 
 }  // namespace dinox

@@ -79,6 +79,43 @@ def _c(t: Tensor) -> Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
+class GemmTimer:
+    """Optional per-launch timing of dinox_gemm with HIP events recorded on the launch stream
+    (bench.py installs one over its timed region to price the dominant kernel against the MFMA
+    roofline).  Keyed by the kernel the dispatcher picks (dinox_gemm_kernel_name)."""
+
+    def __init__(self) -> None:
+        self.records = []      # (kernel name, algorithmic flops, start event, end event)
+        self.pool = []
+
+    def _event(self):
+        return self.pool.pop() if self.pool else torch.cuda.Event(enable_timing=True)
+
+    def launch(self, g, stream) -> None:
+        name = lib.dinox_gemm_kernel_name(C.byref(g)).decode()
+        e0, e1 = self._event(), self._event()
+        e0.record()
+        check(lib.dinox_gemm(C.byref(g), stream), "dinox_gemm")
+        e1.record()
+        self.records.append((name, 2.0 * g.M * g.N * g.K * g.batch, e0, e1))
+
+    def summary(self) -> dict:
+        """{kernel: {"launches", "flops", "ms"}} -- call after a device synchronise."""
+        out: dict = {}
+        for name, fl, e0, e1 in self.records:
+            d = out.setdefault(name, {"launches": 0, "flops": 0.0, "ms": 0.0})
+            d["launches"] += 1
+            d["flops"] += fl
+            d["ms"] += e0.elapsed_time(e1)
+            self.pool += [e0, e1]
+        self.records = []
+        return out
+
+
+GEMM_TIMER: Optional[GemmTimer] = None
+TRACE_KERNELS: Optional[list] = None      # tests set this to a list to learn which GEMM kernel each call used
+
+
 # ------------------------------------------------------------------------------------------
 # raw ops (no autograd)
 # ------------------------------------------------------------------------------------------
@@ -125,7 +162,12 @@ def gemm(A: Tensor, B: Tensor, *, transA=False, transB=False, out: Optional[Tens
         strideA=a2[0] * a2[1] if batched else 0, strideB=(b2[0] * b2[1] if (batched and B.dim() == 3) else 0),
         strideC=M * N, transA=int(transA), transB=int(transB), in_dtype=_code(A.dtype), out_dtype=_code(odt),
         epilogue=epi, alpha=alpha, bias=_p(bias), residual=_p(residual), ldr=N, aux=_p(aux), ldaux=N)
-    check(lib.dinox_gemm(C.byref(g), _stream()), "dinox_gemm")
+    if TRACE_KERNELS is not None:
+        TRACE_KERNELS.append(lib.dinox_gemm_kernel_name(C.byref(g)).decode())
+    if GEMM_TIMER is not None:
+        GEMM_TIMER.launch(g, _stream())
+    else:
+        check(lib.dinox_gemm(C.byref(g), _stream()), "dinox_gemm")
     return out
 
 

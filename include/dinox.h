@@ -91,6 +91,9 @@ typedef struct dinox_gemm_args {
 } dinox_gemm_args;
 
 int dinox_gemm(const dinox_gemm_args* args, void* stream);
+/* Name of the device kernel dinox_gemm would launch for these arguments ("gemm_bf16_nt", "gemm_bf16_tn",
+ * "gemm_f32"); host-only query used by bench.py to attribute per-launch timings.  Static string. */
+const char* dinox_gemm_kernel_name(const dinox_gemm_args* args);
 
 /* out[n] (+)= sum_m x[m][n]   -- bias gradients (autograd of nn.Linear bias, zoo/arch.py:40-41,71-73). */
 int dinox_colsum(const void* x, float* out, int64_t M, int64_t N, int64_t ldx, int dtype, int accumulate,

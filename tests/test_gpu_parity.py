@@ -86,7 +86,11 @@ def test_gemm_bf16_vs_exact(dx, tA, tB, M, N, K):
     A = torch.randn((K, M) if tA else (M, K), generator=g).bfloat16()
     B = torch.randn((K, N) if tB else (N, K), generator=g).bfloat16()
     ref = (A.t() if tA else A).double() @ (B if tB else B.t()).double()
+    ops.TRACE_KERNELS = []
     out = ops.gemm(A.to(DEV), B.to(DEV), transA=bool(tA), transB=bool(tB), out_dtype=torch.float32)
+    used, ops.TRACE_KERNELS = ops.TRACE_KERNELS, None
+    # the MFMA-bf16 kernels must take every aligned NT / TN shape; only (0,1) falls to the fp32-MFMA kernel
+    assert used == [{(0, 0): "gemm_bf16_nt", (1, 1): "gemm_bf16_tn", (0, 1): "gemm_f32"}[(tA, tB)]], used
     close(out, ref, rtol=1e-5, atol=1e-5 * math.sqrt(K), what=f"bf16 gemm {tA}{tB} {M}x{N}x{K}")
     out_b = ops.gemm(A.to(DEV), B.to(DEV), transA=bool(tA), transB=bool(tB))
     assert out_b.dtype == torch.bfloat16

@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py -- training-step throughput of the DINO-X hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W          (one rank per GPU, RCCL)
+
+A "step" is one full optimiser step of the reference loop (scripts/phase5_big_run.py:1692-1802):
+student forward, teacher forward (no grad), DINO centring/sharpening CE + Gram-anchoring loss,
+backward, global grad-norm, AdamW, EMA teacher, centre update -- nothing skipped.
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): ViT-Small/16,
+224x224x3 synthetic 2.5D slice batches, --scale-aware, 256 source samples per GPU = 512 views through
+each network (2 global views per sample: the reference has no multi-crop),
+out_dim 8192, bf16 MFMA operands with fp32 accumulation / residual stream / losses / optimiser.
+Inputs are resident in HBM before the timed region.  Weak scaling: per-GPU batch fixed.
+
+Output: ONE JSON line on rank 0 (see the contract in the task description), with
+  roofline      the dominant kernel (the bf16 MFMA GEMM that carries most FLOPs): algorithmic FLOPs of its
+                launches / their summed duration, measured live with HIP events on the launch stream
+                over the timed region; "step" adds the whole-step figure of BASELINE.md section 2;
+  cpu_baseline  the CPU oracle's same training step timed on this box's host cores (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "dino-x_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch                      # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_BF16_DENSE_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16 MFMA
+
+
+def fwd_flops_per_image(img=224, patch=16, dim=384, depth=12, out_dim=8192, regs=4):
+    """BASELINE.md section 2 / SURVEY.md 8d: F_fwd per image."""
+    P = (img // patch) ** 2
+    N = 1 + P + regs
+    blk = N * dim * 3 * dim + 2 * N * N * dim + N * dim * dim + 8 * N * dim * dim
+    return 2.0 * (P * 3 * patch * patch * dim + depth * blk + dim * dim + dim * out_dim + (N - 1) ** 2 * dim)
+
+
+def cpu_baseline(cfg_kw, out_dim, seconds_budget=25.0):
+    """The oracle's training step (oracle/dinox_oracle.py: fp32 torch-CPU restatement of the reference
+    loop) on a bounded sample of the same workload: same model, B=8 source samples per step."""
+    from oracle import dinox_oracle as O
+    from dinox.hostinfo import usable_cpus
+    cores = usable_cpus()                                  # cpuset + cgroup quota, not os.cpu_count()
+    torch.set_num_threads(cores)
+    B = 8
+    cfg = O.VitCfg(out_dim=out_dim, **cfg_kw)
+    sd = O.random_params(cfg, seed=0)
+    st = O.init_state(cfg, sd)
+    g = torch.Generator().manual_seed(1234)
+    batch = torch.randn(2 * B, 3, cfg.img_size, cfg.img_size, generator=g)
+    sp = torch.rand(B, 3, generator=g) * 0.5 + 0.5
+    sp2 = torch.cat([sp, sp], 0)
+    hp = O.HyperParams()
+    O.train_step(st, batch, sp2, hp)                      # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        O.train_step(st, batch, sp2, hp)
+        n += 1
+        dt = time.perf_counter() - t0
+        if n >= 3 and (dt > seconds_budget or n >= 8):
+            break
+    return {"value": round(B * n / dt, 3), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"oracle train_step (fp32 torch CPU), ViT-S/16 224 scale-aware, B={B} samples/step, {n} timed steps after 1 warm-up"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch-size", type=int, default=256, help="source samples per GPU")
+    ap.add_argument("--fp32", action="store_true", help="parity mode (exact-fp32 MFMA) instead of bf16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket GEMM launches with HIP events")
+    args = ap.parse_args()
+
+    from dinox import ops
+    from dinox.dp import init_process_group
+    from dinox.engine import StepHyperParams, TrainEngine
+    import zoo.arch as arch
+
+    from dinox.hostinfo import usable_cpus
+    torch.set_num_threads(max(1, usable_cpus() // max(1, int(os.environ.get("WORLD_SIZE", "1")))))
+    rank, world, local = init_process_group()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    cfg_kw = dict(img_size=224, patch=16, dim=384, depth=12, heads=6, num_registers=4, scale_aware=True)
+    out_dim, B = 8192, args.batch_size
+    torch.manual_seed(0)
+    student = arch.DinoStudentTeacher(arch.PatchViT(**cfg_kw), out_dim)
+    # exercise the scale branch: the reference zero-inits it, training moves it away from zero
+    torch.nn.init.xavier_uniform_(student.backbone.scale_embed.mlp[2].weight)
+    teacher = arch.DinoStudentTeacher(arch.PatchViT(**cfg_kw), out_dim)
+    teacher.load_state_dict(student.state_dict())
+    amp = None if args.fp32 else torch.bfloat16
+    eng = TrainEngine(student.to(dev), teacher.to(dev), out_dim, StepHyperParams(max_steps=args.steps + args.warmup + 10, warmup_steps=5),
+                      amp_dtype=amp)
+
+    g = torch.Generator().manual_seed(1234 + rank)       # per-rank shard of the synthetic global batch
+    batch = torch.randn(2 * B, 3, 224, 224, generator=g).to(dev)
+    sp = (torch.rand(B, 3, generator=g) * torch.tensor([0.52, 0.52, 4.375]) + torch.tensor([0.46, 0.46, 0.625]))
+    sp2 = torch.cat([sp, sp], 0).to(dev)
+
+    T_START = time.perf_counter()
+
+    def note(msg):
+        if rank == 0:
+            print(f"[bench +{time.perf_counter() - T_START:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    note(f"model + data resident (world {world}, B {B}/GPU, {'fp32' if args.fp32 else 'bf16'})")
+    for i in range(args.warmup):
+        eng.step(batch, sp2)
+        torch.cuda.synchronize()
+        note(f"warm-up step {i} done")
+    timer = None
+    if not args.no_kernel_timing:
+        timer = ops.GemmTimer()
+        ops.GEMM_TIMER = timer
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.step(batch, sp2)
+    barrier()
+    dt = time.perf_counter() - t0
+    ops.GEMM_TIMER = None
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+    note(f"timed region: {args.steps} steps in {dt:.3f}s")
+    scal = eng.scalars()
+    if not (scal["loss"] == scal["loss"]):
+        raise SystemExit("non-finite loss in the timed region")
+
+    kernels = timer.summary() if timer else {}
+    if rank == 0:
+        samples_s = world * B * args.steps / dt
+        gf_sample = 8.0 * fwd_flops_per_image() / 1e9
+        step_tflops = samples_s * gf_sample / 1e3 / world          # per GPU
+        roof = {"bound": "mfma", "achieved": None, "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None}
+        if kernels:
+            dom = max(kernels, key=lambda k: kernels[k]["ms"])
+            d = kernels[dom]
+            ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+            roof.update(kernel=dom, achieved=round(ach, 2), frac=round(ach / PEAK_BF16_DENSE_TFLOPS, 4),
+                        launches_per_step=d["launches"] // args.steps, avg_launch_us=round(1e3 * d["ms"] / d["launches"], 2),
+                        kernel_share_of_step=round(d["ms"] / (dt * 1e3), 4),
+                        all_gemm_kernels={k: {"launches": v["launches"], "ms": round(v["ms"], 3),
+                                              "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in kernels.items()})
+        roof["step"] = {"gflop_per_sample": round(gf_sample, 2), "achieved": round(step_tflops, 2),
+                        "frac": round(step_tflops / PEAK_BF16_DENSE_TFLOPS, 4)}
+        line = {
+            "metric": "training images/sec (source samples; 2 global views each) ViT-S/16 224px bs256/GPU",
+            "value": round(samples_s, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.fp32 else "bf16", "data": "synthetic",
+            "config": {"workload": "ViT-S/16 224x224x3 2.5D slice stacks, scale-aware, 2 views/sample, DINO+Gram loss, AdamW+EMA",
+                       "per_gpu_batch": B, "global_batch": B * world, "views_per_step": 2 * B * world, "tokens": 201, "out_dim": out_dim,
+                       "parallelism": f"dp{world}", "views_per_s": round(2 * samples_s, 2),
+                       "loss": round(scal["loss"], 5), "grad_norm": round(scal["grad_norm"], 5)},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            note("timing the CPU oracle (cpu_baseline) ...")
+            line["cpu_baseline"] = cpu_baseline(cfg_kw, out_dim)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -14,6 +14,10 @@ for p in (ROOT, PKG):
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+from dinox.hostinfo import usable_cpus  # noqa: E402
+
+torch.set_num_threads(min(8, usable_cpus()))
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

@@ -266,10 +266,13 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_bf16_tn(GemmParams p, int 
 }
 
 static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+bool gemm_bf16_nt_glds_ok(const GemmParams& p);
+int launch_gemm_bf16_nt_glds(const GemmParams& p, hipStream_t st);
 
 const char* gemm_bf16_variant(const GemmParams& p) {
   if (p.in_dtype != DINOX_BF16) return nullptr;
   if (!aligned16(p.A) || !aligned16(p.B) || (p.lda & 7) || (p.ldb & 7) || (p.strideA & 7) || (p.strideB & 7)) return nullptr;
+  if (gemm_bf16_nt_glds_ok(p)) return "gemm_bf16_nt_glds";
   if (p.transA == 0 && p.transB == 0 && (p.K & 7) == 0) return "gemm_bf16_nt";
   if (p.transA == 1 && p.transB == 1 && (p.M & 7) == 0 && (p.N & 7) == 0) return "gemm_bf16_tn";
   return nullptr;
@@ -278,6 +281,7 @@ const char* gemm_bf16_variant(const GemmParams& p) {
 int launch_gemm_bf16(const GemmParams& p, hipStream_t st) {
   const char* v = gemm_bf16_variant(p);
   if (!v) return DINOX_EUNSUPPORTED;
+  if (v[12] == '_') return launch_gemm_bf16_nt_glds(p, st);   // "gemm_bf16_nt_glds"
   const int tiles_m = (int)ceil_div(p.M, GB_BM), tiles_n = (int)ceil_div(p.N, GB_BN);
   const int64_t ntile = (int64_t)tiles_m * tiles_n;
   if (ntile > 0x7fffffff || p.batch > 65535) return DINOX_EUNSUPPORTED;

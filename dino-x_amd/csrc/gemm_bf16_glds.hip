@@ -1,0 +1,234 @@
+// gemm_bf16_glds.hip -- second-generation NT bf16 MFMA GEMM: direct-to-LDS operand staging and a
+// row-major, vectorised fused epilogue.
+//
+// Why (rocprof, round 1): the products of this path have tiny K (384..1536) and huge M (~1e5 tokens), so a
+// 128x128 tile runs only 6..24 K-steps and the per-tile prologue/epilogue is as long as its MFMA work.  The
+// first-generation kernel (gemm_bf16.hip) staged operands through VGPRs (ds_write_b128 moves ~79 B/clk/CU,
+// MI355X_MICROARCH.md LDS table: slower than the MFMAs it feeds) and stored the accumulator column-wise
+// (64-B segments, scalar epilogue math with run-time flag tests).  Here:
+//   * operands go global -> LDS with global_load_lds_dwordx4 (16 B/lane, no VGPRs, no ds_write); the LDS
+//     image stays lane-linear and the bank swizzle (chunk ^ ((row>>1)&7)) is applied to the per-lane SOURCE
+//     address and to the ds_read_b128 address (cdna_hip_programming.md rule 21);
+//   * after the K loop each wave parks its 64x64 fp32 accumulator block in its own 16 KiB of the (now idle)
+//     LDS stages, XOR-swizzled, and re-reads it row-major: every lane then owns 8 consecutive outputs of a
+//     row, so bias / GELU / GELU' / residual use 16-B vector loads and the stores are whole 128-B (bf16) or
+//     256-B (fp32) row segments;
+//   * epilogue variants are compile-time (no flag tests in the inner code) and GELU uses a 1.5e-7-accurate
+//     rational erf instead of erff.
+// Envelope: K % 64 == 0, N % 8 == 0, 16-B aligned operands/outputs; anything else takes gemm_bf16_nt.
+#include "common.h"
+#include "gemm_common.h"
+
+namespace dinox {
+
+constexpr int GG_BM = 128, GG_BN = 128, GG_BK = 64, GG_THREADS = 256;
+constexpr int GG_TILE = 128 * 64 * 2;  // bytes per operand tile per stage
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_void;
+
+__device__ __forceinline__ int gg_xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+enum { GG_PLAIN = 0, GG_GELU = 1, GG_DGELU = 2 };
+
+template <int OUT_DT, int ACT, bool RES>
+__global__ __launch_bounds__(GG_THREADS, 2) void gemm_bf16_nt_glds(GemmParams p, int tiles_m, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wv >> 1, wc = wv & 1;
+  const int tile = gg_xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  const int64_t m0 = (int64_t)tm * GG_BM, n0 = (int64_t)tn * GG_BN;
+  const int64_t bz = blockIdx.y;
+  const bf16_t* A = (const bf16_t*)p.A + bz * p.strideA;
+  const bf16_t* B = (const bf16_t*)p.B + bz * p.strideB;
+
+  // Per-lane source pointers of this wave's 4 + 4 staging instructions (each moves 8 rows x 128 B).
+  // LDS slot (row, c') of a tile receives logical chunk c = c' ^ ((row>>1)&7) of that row.
+  const bf16_t* asrc[4];
+  const bf16_t* bsrc[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int row = (wv * 4 + q) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    int64_t gm = m0 + row, gn = n0 + row;
+    gm = gm < p.M ? gm : p.M - 1;
+    gn = gn < p.N ? gn : p.N - 1;
+    asrc[q] = A + gm * p.lda + c * 8;
+    bsrc[q] = B + gn * p.ldb + c * 8;
+  }
+  auto stage = [&](int buf, int64_t k0) {
+    char* sa = smem + buf * 2 * GG_TILE + wv * 4096;
+    char* sb = sa + GG_TILE;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      __builtin_amdgcn_global_load_lds((gbl_void*)(asrc[q] + k0), (lds_void*)(sa + q * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void*)(bsrc[q] + k0), (lds_void*)(sb + q * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nk = (int)(p.K / GG_BK);
+  stage(0, 0);
+  __syncthreads();
+  const int frow = lane & 31, fh = lane >> 5;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) stage(cur ^ 1, (int64_t)(kt + 1) * GG_BK);
+    const char* sa = smem + cur * 2 * GG_TILE;
+    const char* sb = sa + GG_TILE;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 af[2], bfr[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int ra = wr * 64 + i * 32 + frow, rb = wc * 64 + i * 32 + frow;
+        const int kc = 2 * ks + fh;
+        af[i] = *reinterpret_cast<const bf16x8*>(sa + ra * 128 + ((kc ^ ((ra >> 1) & 7)) << 4));
+        bfr[i] = *reinterpret_cast<const bf16x8*>(sb + rb * 128 + ((kc ^ ((rb >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: park the wave's 64x64 block in LDS (row = 256 B, 16-B chunks XOR (row&15)), re-read by rows
+  char* park = smem + wv * 16384;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+        const int n = j * 32 + frow;
+        *reinterpret_cast<float*>(park + row * 256 + ((((n >> 2) ^ (row & 15))) << 4) + (n & 3) * 4) = acc[i][j][e];
+      }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+
+  const int c8 = lane & 7;
+  const int64_t n = n0 + wc * 64 + c8 * 8;
+  if (n >= p.N) return;                                  // N % 8 == 0: a lane's 8 columns are all in or all out
+  float bias[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) bias[u] = 0.f;
+  if (p.epilogue & DINOX_EPI_BIAS) {
+    const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n), b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
+    bias[0] = b0.x; bias[1] = b0.y; bias[2] = b0.z; bias[3] = b0.w;
+    bias[4] = b1.x; bias[5] = b1.y; bias[6] = b1.z; bias[7] = b1.w;
+  }
+  const float alpha = p.alpha;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int row = it * 8 + (lane >> 3);
+    const int64_t m = m0 + wr * 64 + row;
+    const float4 lo = *reinterpret_cast<const float4*>(park + row * 256 + (((2 * c8) ^ (row & 15)) << 4));
+    const float4 hi = *reinterpret_cast<const float4*>(park + row * 256 + (((2 * c8 + 1) ^ (row & 15)) << 4));
+    if (m >= p.M) continue;
+    float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = v[u] * alpha + bias[u];
+    if (ACT == GG_GELU) {
+      if (p.aux) {
+        const int64_t ai = bz * p.M * p.ldaux + m * p.ldaux + n;
+        if (OUT_DT == DINOX_BF16) {
+          s16x8 pk;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) pk[u] = (short)f32_to_bf16(v[u]);
+          *reinterpret_cast<s16x8*>((bf16_t*)p.aux + ai) = pk;
+        } else {
+          *reinterpret_cast<float4*>((float*)p.aux + ai) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>((float*)p.aux + ai + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = gelu_fast(v[u]);
+    }
+    if (ACT == GG_DGELU) {
+      const int64_t ai = bz * p.M * p.ldaux + m * p.ldaux + n;
+      float x[8];
+      if (OUT_DT == DINOX_BF16) {
+        const s16x8 pk = *reinterpret_cast<const s16x8*>((const bf16_t*)p.aux + ai);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = bf16_to_f32((bf16_t)pk[u]);
+      } else {
+        const float4 x0 = *reinterpret_cast<const float4*>((const float*)p.aux + ai), x1 = *reinterpret_cast<const float4*>((const float*)p.aux + ai + 4);
+        x[0] = x0.x; x[1] = x0.y; x[2] = x0.z; x[3] = x0.w; x[4] = x1.x; x[5] = x1.y; x[6] = x1.z; x[7] = x1.w;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] *= gelu_fast_grad(x[u]);
+    }
+    if (RES) {
+      const float* rp = p.residual + bz * p.M * p.ldr + m * p.ldr + n;
+      const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
+      v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
+      v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+    }
+    const int64_t ci = bz * p.strideC + m * p.ldc + n;
+    if (OUT_DT == DINOX_BF16) {
+      s16x8 pk;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) pk[u] = (short)f32_to_bf16(v[u]);
+      *reinterpret_cast<s16x8*>((bf16_t*)p.C + ci) = pk;
+    } else {
+      *reinterpret_cast<float4*>((float*)p.C + ci) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>((float*)p.C + ci + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+  }
+}
+
+static bool al16(const void* q) { return (((uintptr_t)q) & 15) == 0; }
+
+bool gemm_bf16_nt_glds_ok(const GemmParams& p) {
+  if (p.in_dtype != DINOX_BF16 || p.transA || p.transB) return false;
+  if ((p.K % GG_BK) || (p.N & 7) || (p.lda & 7) || (p.ldb & 7) || (p.strideA & 7) || (p.strideB & 7)) return false;
+  if (!al16(p.A) || !al16(p.B) || !al16(p.C)) return false;
+  const int esz = p.out_dtype == DINOX_BF16 ? 2 : 4;
+  if ((p.ldc * esz) & 15 || (p.strideC * esz) & 15) return false;
+  if (p.epilogue & DINOX_EPI_ACCUM) return false;
+  if ((p.epilogue & DINOX_EPI_BIAS) && !al16(p.bias)) return false;
+  if ((p.epilogue & DINOX_EPI_RESIDUAL) && (!al16(p.residual) || (p.ldr & 3))) return false;
+  if ((p.epilogue & (DINOX_EPI_GELU | DINOX_EPI_DGELU)) && p.aux && (!al16(p.aux) || ((p.ldaux * esz) & 15))) return false;
+  if (p.batch > 65535) return false;
+  return true;
+}
+
+int launch_gemm_bf16_nt_glds(const GemmParams& p, hipStream_t st) {
+  const int tiles_m = (int)ceil_div(p.M, GG_BM), tiles_n = (int)ceil_div(p.N, GG_BN);
+  const int64_t ntile = (int64_t)tiles_m * tiles_n;
+  if (ntile > 0x7fffffff) return DINOX_EUNSUPPORTED;
+  dim3 grid((unsigned)ntile, (unsigned)p.batch);
+  const size_t lds = 4 * GG_TILE;
+  const int act = (p.epilogue & DINOX_EPI_GELU) ? GG_GELU : (p.epilogue & DINOX_EPI_DGELU) ? GG_DGELU : GG_PLAIN;
+  const bool res = (p.epilogue & DINOX_EPI_RESIDUAL) != 0;
+#define GG(OUT, ACT, RES) hipLaunchKernelGGL((gemm_bf16_nt_glds<OUT, ACT, RES>), grid, dim3(GG_THREADS), lds, st, p, tiles_m, tiles_n)
+#define GG_ACT(OUT, RES)                                                                  \
+  do {                                                                                    \
+    if (act == GG_GELU) GG(OUT, GG_GELU, RES); else if (act == GG_DGELU) GG(OUT, GG_DGELU, RES); else GG(OUT, GG_PLAIN, RES); \
+  } while (0)
+  if (p.out_dtype == DINOX_BF16) {
+    if (res) GG_ACT(DINOX_BF16, true); else GG_ACT(DINOX_BF16, false);
+  } else {
+    if (res) GG_ACT(DINOX_F32, true); else GG_ACT(DINOX_F32, false);
+  }
+#undef GG_ACT
+#undef GG
+  return check_launch("gemm_bf16_nt_glds");
+}
+
+}  // namespace dinox

@@ -75,7 +75,7 @@ def test_gemm_f32_epilogues_and_batch(dx):
     close(out2, c0.double() + torch.einsum("bmk,bnk->bmn", A.double(), B.double()) * dg, 1e-5, 1e-5, "dgelu+accum")
 
 
-@pytest.mark.parametrize("tA,tB,M,N,K", [(0, 0, 256, 384, 384), (0, 0, 201 * 4, 1152, 384), (0, 0, 130, 72, 200),
+@pytest.mark.parametrize("tA,tB,M,N,K", [(0, 0, 256, 384, 384), (0, 0, 201 * 4, 1152, 384), (0, 0, 130, 72, 200), (0, 0, 77, 200, 128),
                                          (1, 1, 384, 1536, 804), (1, 1, 200, 384, 200), (1, 1, 96, 72, 1000),
                                          (0, 1, 64, 64, 64), (0, 0, 512, 8192, 384)])
 def test_gemm_bf16_vs_exact(dx, tA, tB, M, N, K):
@@ -90,7 +90,8 @@ def test_gemm_bf16_vs_exact(dx, tA, tB, M, N, K):
     out = ops.gemm(A.to(DEV), B.to(DEV), transA=bool(tA), transB=bool(tB), out_dtype=torch.float32)
     used, ops.TRACE_KERNELS = ops.TRACE_KERNELS, None
     # the MFMA-bf16 kernels must take every aligned NT / TN shape; only (0,1) falls to the fp32-MFMA kernel
-    assert used == [{(0, 0): "gemm_bf16_nt", (1, 1): "gemm_bf16_tn", (0, 1): "gemm_f32"}[(tA, tB)]], used
+    want = {(0, 0): "gemm_bf16_nt_glds" if (K % 64 == 0 and N % 8 == 0) else "gemm_bf16_nt", (1, 1): "gemm_bf16_tn", (0, 1): "gemm_f32"}[(tA, tB)]
+    assert used == [want], used
     close(out, ref, rtol=1e-5, atol=1e-5 * math.sqrt(K), what=f"bf16 gemm {tA}{tB} {M}x{N}x{K}")
     out_b = ops.gemm(A.to(DEV), B.to(DEV), transA=bool(tA), transB=bool(tB))
     assert out_b.dtype == torch.bfloat16

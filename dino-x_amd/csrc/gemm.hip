@@ -36,6 +36,7 @@ static void to_params(const dinox_gemm_args* a, GemmParams& p) {
   p.in_dtype = a->in_dtype; p.out_dtype = a->out_dtype; p.epilogue = a->epilogue;
   p.alpha = a->alpha;
   p.bias = a->bias; p.residual = a->residual; p.ldr = a->ldr; p.aux = a->aux; p.ldaux = a->ldaux;
+  p.colsum = a->colsum;
 }
 
 extern "C" const char* dinox_gemm_kernel_name(const dinox_gemm_args* a) {
@@ -62,13 +63,18 @@ extern "C" int dinox_gemm(const dinox_gemm_args* a, void* stream) {
   DX_REQUIRE(!(e & DINOX_EPI_GELU) || !a->aux || a->ldaux >= a->N, DINOX_EINVAL, "gemm: GELU aux ldaux too small");
   DX_REQUIRE(!((e & DINOX_EPI_GELU) && (e & DINOX_EPI_DGELU)), DINOX_EINVAL, "gemm: GELU and DGELU are exclusive");
   DX_REQUIRE(!(e & DINOX_EPI_ACCUM) || a->out_dtype == DINOX_F32, DINOX_EINVAL, "gemm: ACCUM needs fp32 C");
+  DX_REQUIRE(!a->colsum || (a->transA && a->batch == 1), DINOX_EINVAL, "gemm: colsum needs transA=1 and batch=1");
   GemmParams p;
   to_params(a, p);
   hipStream_t st = as_stream(stream);
   if (p.in_dtype == DINOX_BF16) {
-    const int rc = launch_gemm_bf16(p, st);
+    const int rc = launch_gemm_bf16(p, st);          // the TN kernel produces colsum itself
     if (rc != DINOX_EUNSUPPORTED) return rc;
     // shape/layout outside the MFMA-bf16 kernel's envelope: exact-fp32 MFMA on the bf16 values.
+  }
+  if (p.colsum) {                                    // A is stored [K][M]: its column sums are the wanted vector
+    const int rc = dinox_colsum(p.A, p.colsum, p.K, p.M, p.lda, p.in_dtype, 0, stream);
+    if (rc) return rc;
   }
   return launch_gemm_f32(p, st);
 }

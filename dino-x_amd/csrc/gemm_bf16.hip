@@ -214,6 +214,19 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_bf16_tn(GemmParams p, int 
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const int nk = kend > kbeg ? (int)ceil_div(kend - kbeg, GB_BK) : 0;
+  // Bias gradient riding along: colsum[m] = sum_k A[k][m] = (A^T . 1)[m].  The wc == 0 waves multiply their A
+  // fragments with an all-ones B fragment on every tiles_n-th K-step (k-steps are dealt round-robin over the
+  // N-tiles of a row panel, so the extra MFMAs are spread evenly over the grid and no VALU work is added).
+  const bool cs_wave = p.colsum != nullptr && wc == 0;
+  f32x16 csacc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) csacc[i][e] = 0.f;
+  s16x8 ones_s;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones_s[j] = (short)0x3F80;   // bf16 1.0
+  const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_s);
   TnStage st;
   if (nk > 0) {
     tn_load(st, A, B, p.lda, p.ldb, m0, n0, kbeg, kend, p.M, p.N);
@@ -237,12 +250,26 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_bf16_tn(GemmParams p, int 
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      if (cs_wave && (kt % tiles_n) == tn) {                 // wave-uniform
+        csacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], ones, csacc[0], 0, 0, 0);
+        csacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], ones, csacc[1], 0, 0, 0);
+      }
     }
     if (kt + 1 < nk) {
       char* na = smem + (cur ^ 1) * 2 * GB_TILE_BYTES;
       tn_store(st, na, na + GB_TILE_BYTES);
     }
     __syncthreads();
+  }
+
+  if (cs_wave && (lane & 31) == 0) {   // every column of csacc holds the same sums: lanes 0 and 32 own all 32 rows
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int64_t m = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (m < p.M) atomicAdd(p.colsum + m, csacc[i][e]);
+      }
   }
 
 #pragma unroll
@@ -316,6 +343,10 @@ int launch_gemm_bf16(const GemmParams& p, hipStream_t st) {
       splits = 1;
       kps = ceil_div(p.K, GB_BK) * GB_BK;
     }
+  }
+  if (p.colsum) {
+    hipError_t e = hipMemsetAsync(p.colsum, 0, (size_t)p.M * sizeof(float), st);
+    if (e != hipSuccess) return fail((int)e, "gemm_bf16_tn: memset colsum: %s", hipGetErrorString(e));
   }
   dim3 grid((unsigned)ntile, (unsigned)(p.batch * splits));
   if (p.out_dtype == DINOX_F32)

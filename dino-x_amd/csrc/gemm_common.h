@@ -18,6 +18,7 @@ struct GemmParams {
   int64_t ldr;
   void* aux;
   int64_t ldaux;
+  float* colsum;
 };
 
 // One output element: BIAS -> GELU(+aux write) -> DGELU(aux read) -> RESIDUAL -> ACCUM -> store.

@@ -226,13 +226,22 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_generic(const void* __restr
   for (int c = threadIdx.x; c < 2 * dim; c += LN_THREADS) out[c] = lds[c];
 }
 
-__global__ void ln_bwd_reduce(const float* __restrict__ ws, float* __restrict__ dw, float* __restrict__ db, int parts,
-                              int dim) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= 2 * dim) return;
+// Stage 2: out[c] = sum_p ws[p][c].  grid (2*dim/64, 16): thread (c, g) sums parts p == 4*blockIdx.y + g (mod 64),
+// the 4 groups meet in LDS and the 16 grid rows through fp32 atomics on the zeroed outputs.
+__global__ __launch_bounds__(256) void ln_bwd_reduce(const float* __restrict__ ws, float* __restrict__ dw, float* __restrict__ db,
+                                                     int parts, int dim) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   float s = 0.f;
-  for (int p = 0; p < parts; ++p) s += ws[(size_t)p * 2 * dim + c];
-  if (c < dim) dw[c] = s; else db[c - dim] = s;
+  if (c < 2 * dim)
+    for (int p = blockIdx.y * 4 + g; p < parts; p += 64) s += ws[(size_t)p * 2 * dim + c];
+  red[g][cl] = s;
+  __syncthreads();
+  if (g == 0 && c < 2 * dim) {
+    const float t = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+    atomicAdd(c < dim ? &dw[c] : &db[c - dim], t);
+  }
 }
 
 static int ln_parts(int64_t rows) {
@@ -306,6 +315,9 @@ extern "C" int dinox_layernorm_bwd(const void* dy, const float* x, const float* 
 #undef LN_BWD
   int rc = check_launch("layernorm_bwd");
   if (rc) return rc;
-  hipLaunchKernelGGL(ln_bwd_reduce, dim3((unsigned)ceil_div(2 * dim, 256)), dim3(256), 0, st, wsf, dw, db, parts, dim);
+  hipError_t me = hipMemsetAsync(dw, 0, (size_t)dim * sizeof(float), st);
+  if (me == hipSuccess) me = hipMemsetAsync(db, 0, (size_t)dim * sizeof(float), st);
+  if (me != hipSuccess) return fail((int)me, "layernorm_bwd: memset: %s", hipGetErrorString(me));
+  hipLaunchKernelGGL(ln_bwd_reduce, dim3((unsigned)ceil_div(2 * dim, 64), 16), dim3(256), 0, st, wsf, dw, db, parts, dim);
   return check_launch("layernorm_bwd_reduce");
 }

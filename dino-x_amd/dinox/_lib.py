@@ -26,7 +26,7 @@ class GemmArgs(C.Structure):
         ("batch", i64), ("strideA", i64), ("strideB", i64), ("strideC", i64),
         ("transA", i32), ("transB", i32), ("in_dtype", i32), ("out_dtype", i32), ("epilogue", i32),
         ("alpha", f32),
-        ("bias", vp), ("residual", vp), ("ldr", i64), ("aux", vp), ("ldaux", i64),
+        ("bias", vp), ("residual", vp), ("ldr", i64), ("aux", vp), ("ldaux", i64), ("colsum", vp),
     ]
 
 

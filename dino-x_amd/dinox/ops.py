@@ -121,7 +121,8 @@ TRACE_KERNELS: Optional[list] = None      # tests set this to a list to learn wh
 # ------------------------------------------------------------------------------------------
 def gemm(A: Tensor, B: Tensor, *, transA=False, transB=False, out: Optional[Tensor] = None,
          out_dtype: Optional[torch.dtype] = None, bias: Optional[Tensor] = None, gelu=False, aux: Optional[Tensor] = None,
-         dgelu=False, residual: Optional[Tensor] = None, accumulate=False, alpha: float = 1.0) -> Tensor:
+         dgelu=False, residual: Optional[Tensor] = None, accumulate=False, alpha: float = 1.0,
+         colsum_out: Optional[Tensor] = None) -> Tensor:
     """C = epilogue(alpha * op(A) op(B)^T); A: [M,K] (or [K,M] if transA), B: [N,K] (or [K,N] if transB).
     3-D operands are batched over dim 0 (B may be 2-D = shared)."""
     _need_cuda(A, B)
@@ -157,11 +158,13 @@ def gemm(A: Tensor, B: Tensor, *, transA=False, transB=False, out: Optional[Tens
         assert residual.dtype == torch.float32 and residual.is_contiguous() and residual.numel() == batch * M * N
     if accumulate:
         epi |= EPI_ACCUM
+    if colsum_out is not None:
+        assert transA and not batched and colsum_out.dtype == torch.float32 and colsum_out.numel() == M and colsum_out.is_contiguous()
     g = GemmArgs(
         A=_p(A), B=_p(B), C=_p(out), M=M, N=N, K=K, lda=a2[1], ldb=b2[1], ldc=N, batch=batch,
         strideA=a2[0] * a2[1] if batched else 0, strideB=(b2[0] * b2[1] if (batched and B.dim() == 3) else 0),
         strideC=M * N, transA=int(transA), transB=int(transB), in_dtype=_code(A.dtype), out_dtype=_code(odt),
-        epilogue=epi, alpha=alpha, bias=_p(bias), residual=_p(residual), ldr=N, aux=_p(aux), ldaux=N)
+        epilogue=epi, alpha=alpha, bias=_p(bias), residual=_p(residual), ldr=N, aux=_p(aux), ldaux=N, colsum=_p(colsum_out))
     if TRACE_KERNELS is not None:
         TRACE_KERNELS.append(lib.dinox_gemm_kernel_name(C.byref(g)).decode())
     if GEMM_TIMER is not None:
@@ -339,9 +342,11 @@ class LinearFn(torch.autograd.Function):
                 if dx.dtype != ctx.xdtype:
                     dx = dx.to(ctx.xdtype)
             dx = dx.reshape(ctx.xshape)
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            dw = gemm(dy2, x2, transA=True, transB=True, out_dtype=torch.float32)        # dy^T [N,M] . x [M,K]
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty(w.shape[0], dtype=torch.float32, device=dy2.device) if want_db else None
+            dw = gemm(dy2, x2, transA=True, transB=True, out_dtype=torch.float32, colsum_out=db)   # dy^T [N,M] . x [M,K] (+ db)
+        elif want_db:
             db = colsum(dy2)
         dres = dy if ctx.has_res else None
         return dx, dw, db, dres, None
@@ -377,8 +382,8 @@ class MlpFn(torch.autograd.Function):
             dpre = gemm(dy2, w2.detach(), transB=True, dgelu=True, aux=pre, out_dtype=dt)
         else:
             dpre = gemm(dy2, weight_operand(w2, dt, transposed=True), dgelu=True, aux=pre, out_dtype=dt)
-        dw2 = gemm(dy2, act, transA=True, transB=True, out_dtype=torch.float32)
-        db2 = colsum(dy2) if ctx.has_b2 else None
+        db2 = torch.empty(w2.shape[0], dtype=torch.float32, device=dy2.device) if ctx.has_b2 else None
+        dw2 = gemm(dy2, act, transA=True, transB=True, out_dtype=torch.float32, colsum_out=db2)
         dx = None
         if ctx.needs_input_grad[0]:
             if dt == torch.float32:
@@ -388,8 +393,8 @@ class MlpFn(torch.autograd.Function):
             if dx.dtype != ctx.xdtype:
                 dx = dx.to(ctx.xdtype)
             dx = dx.reshape(ctx.xshape)
-        dw1 = gemm(dpre, x2, transA=True, transB=True, out_dtype=torch.float32)
-        db1 = colsum(dpre) if ctx.has_b1 else None
+        db1 = torch.empty(w1.shape[0], dtype=torch.float32, device=dy2.device) if ctx.has_b1 else None
+        dw1 = gemm(dpre, x2, transA=True, transB=True, out_dtype=torch.float32, colsum_out=db1)
         return dx, dw1, db1, dw2, db2, (dy if ctx.has_res else None), None
 
 
@@ -465,8 +470,8 @@ class TokensFn(torch.autograd.Function):
         dscale = torch.empty((V, 1, D), dtype=torch.float32, device=dev) if ctx.has_scale else None
         check(lib.dinox_tokens_bwd(_p(dtok), _p(dpatches), _p(dcls), _p(dpos), _p(dregs), _p(dscale), V, P, R, D, _code(dt), _stream()),
               "dinox_tokens_bwd")
-        dw = gemm(dpatches, u, transA=True, transB=True, out_dtype=torch.float32).reshape(ctx.pw_shape)
-        db = colsum(dpatches)
+        db = torch.empty(D, dtype=torch.float32, device=dev)
+        dw = gemm(dpatches, u, transA=True, transB=True, out_dtype=torch.float32, colsum_out=db).reshape(ctx.pw_shape)
         return None, dw, db, dcls, dpos, dregs, dscale, None
 
 

@@ -88,6 +88,8 @@ typedef struct dinox_gemm_args {
   int64_t ldr;
   void* aux;
   int64_t ldaux;
+  float* colsum;                       /* optional, transA = 1 only: colsum[m] = sum_k A(m,k) (overwritten) -- the bias
+                                        * gradient sum_rows(dY) rides along the dW = dY^T X product that already streams dY */
 } dinox_gemm_args;
 
 int dinox_gemm(const dinox_gemm_args* args, void* stream);

@@ -117,6 +117,19 @@ def test_gemm_bf16_epilogues(dx):
     assert rel_l2(d.float(), (A.double() @ B.double().t()) * dg) < 5e-3
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,nout,kin", [(804, 384, 256), (1000, 136, 72), (77, 64, 64)])
+def test_gemm_tn_fused_colsum(dx, dt, rows, nout, kin):
+    """dW = dY^T X with the bias gradient colsum(dY) riding along (TN kernel) or via the fallback."""
+    ops, _ = dx
+    g = torch.Generator().manual_seed(rows)
+    dy, x = torch.randn(rows, nout, generator=g).to(dt), torch.randn(rows, kin, generator=g).to(dt)
+    db = torch.full((nout,), 7.0, device=DEV)            # must be overwritten, not accumulated
+    dw = ops.gemm(dy.to(DEV), x.to(DEV), transA=True, transB=True, out_dtype=torch.float32, colsum_out=db)
+    close(dw, dy.double().t() @ x.double(), 1e-5, 1e-4 * math.sqrt(rows), "dW")
+    close(db, dy.double().sum(0), 1e-5, 1e-4 * math.sqrt(rows), "db")
+
+
 def test_colsum(dx):
     ops, _ = dx
     x = torch.randn(1003, 130)

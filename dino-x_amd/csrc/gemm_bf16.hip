@@ -292,6 +292,133 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_bf16_tn(GemmParams p, int 
   }
 }
 
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+template <int OUT_DT>
+__global__ __launch_bounds__(GB_THREADS, 2) void gemm_bf16_tn_dma(GemmParams p, int tiles_m, int tiles_n, int splits,
+                                                              int64_t k_per_split) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wr = wv >> 1, wc = wv & 1;
+  const int ntile = tiles_m * tiles_n;
+  const int tile = xcd_remap(blockIdx.x, ntile);
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  const int64_t m0 = (int64_t)tm * GB_BM, n0 = (int64_t)tn * GB_BN;
+  const int64_t bz = blockIdx.y / splits;
+  const int split = blockIdx.y % splits;
+  const int64_t kbeg = (int64_t)split * k_per_split;
+  int64_t kend = kbeg + k_per_split;
+  if (kend > p.K) kend = p.K;
+  const bf16_t* A = (const bf16_t*)p.A + bz * p.strideA;
+  const bf16_t* B = (const bf16_t*)p.B + bz * p.strideB;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nk = kend > kbeg ? (int)ceil_div(kend - kbeg, GB_BK) : 0;
+  // Bias gradient riding along: colsum[m] = sum_k A[k][m] = (A^T . 1)[m].  The wc == 0 waves multiply their A
+  // fragments with an all-ones B fragment on every tiles_n-th K-step (k-steps are dealt round-robin over the
+  // N-tiles of a row panel, so the extra MFMAs are spread evenly over the grid and no VALU work is added).
+  const bool cs_wave = p.colsum != nullptr && wc == 0;
+  f32x16 csacc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) csacc[i][e] = 0.f;
+  s16x8 ones_s;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones_s[j] = (short)0x3F80;   // bf16 1.0
+  const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_s);
+  // Direct-to-LDS staging: each wave issues 4 + 4 buffer_load_dwordx4 ... lds per K-step, every one moving 4 k-rows
+  // x 256 B.  LDS slot (r, chunk') receives logical chunk c = (((chunk'>>2) ^ (r&3))<<2) | (chunk'&3) (the granule
+  // swizzle, applied to the SOURCE address).  Rows k >= K fall outside the buffer descriptor and read as zeros.
+  const int wvu = __builtin_amdgcn_readfirstlane(wv);
+  const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)(p.K * p.lda * 2), 0x00020000);
+  const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (int)(p.K * p.ldb * 2), 0x00020000);
+  unsigned voffA[4], voffB[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = (wvu * 4 + q) * 4 + (lane >> 4);
+    const int cp = lane & 15;
+    const int c = (((cp >> 2) ^ (r & 3)) << 2) | (cp & 3);
+    int64_t ma = m0 + c * 8, nb = n0 + c * 8;
+    ma = ma < p.M ? ma : p.M - 8;                      // columns past the edge only feed rows/cols that are never stored
+    nb = nb < p.N ? nb : p.N - 8;
+    voffA[q] = (unsigned)(((kbeg + r) * p.lda + ma) * 2);
+    voffB[q] = (unsigned)(((kbeg + r) * p.ldb + nb) * 2);
+  }
+  const unsigned stepA = (unsigned)(GB_BK * p.lda * 2), stepB = (unsigned)(GB_BK * p.ldb * 2);
+  auto stage = [&](int buf, int kt) {
+    char* sa = smem + buf * 2 * GB_TILE_BYTES + wvu * 4096;
+    char* sb = sa + GB_TILE_BYTES;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)(sa + q * 1024), 16, voffA[q] + kt * stepA, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)(sb + q * 1024), 16, voffB[q] + kt * stepB, 0, 0, 0);
+    }
+  };
+  if (nk > 0) stage(0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    const char* sa = smem + cur * 2 * GB_TILE_BYTES;
+    const char* sb = sa + GB_TILE_BYTES;
+    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 af[2], bfr[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[i] = tn_frag(sa, ks * 16, wr * 64 + i * 32, lane);
+        bfr[i] = tn_frag(sb, ks * 16, wc * 64 + i * 32, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      if (cs_wave && (kt % tiles_n) == tn) {                 // wave-uniform
+        csacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], ones, csacc[0], 0, 0, 0);
+        csacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], ones, csacc[1], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  if (cs_wave && (lane & 31) == 0) {   // every column of csacc holds the same sums: lanes 0 and 32 own all 32 rows
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int64_t m = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (m < p.M) atomicAdd(p.colsum + m, csacc[i][e]);
+      }
+  }
+
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int64_t n = n0 + wc * 64 + j * 32 + (lane & 31);
+    if (n >= p.N) continue;
+    const float bias = (p.epilogue & DINOX_EPI_BIAS) ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int64_t m = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (m >= p.M) continue;
+        if (splits > 1)
+          atomicAdd((float*)p.C + bz * p.strideC + m * p.ldc + n, acc[i][j][e] * p.alpha);  // C zeroed / accumulating
+        else
+          epilogue_store<OUT_DT>(p, bz, m, n, acc[i][j][e], bias);
+      }
+    }
+  }
+}
+
 static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 bool gemm_bf16_nt_glds_ok(const GemmParams& p);
 int launch_gemm_bf16_nt_glds(const GemmParams& p, hipStream_t st);
@@ -301,14 +428,17 @@ const char* gemm_bf16_variant(const GemmParams& p) {
   if (!aligned16(p.A) || !aligned16(p.B) || (p.lda & 7) || (p.ldb & 7) || (p.strideA & 7) || (p.strideB & 7)) return nullptr;
   if (gemm_bf16_nt_glds_ok(p)) return "gemm_bf16_nt_glds";
   if (p.transA == 0 && p.transB == 0 && (p.K & 7) == 0) return "gemm_bf16_nt";
-  if (p.transA == 1 && p.transB == 1 && (p.M & 7) == 0 && (p.N & 7) == 0) return "gemm_bf16_tn";
+  if (p.transA == 1 && p.transB == 1 && (p.M & 7) == 0 && (p.N & 7) == 0) {
+    const bool small = p.K * p.lda * 2 < (int64_t)0x7fffffff && p.K * p.ldb * 2 < (int64_t)0x7fffffff && p.M >= 8 && p.N >= 8;
+    return small ? "gemm_bf16_tn_dma" : "gemm_bf16_tn";
+  }
   return nullptr;
 }
 
 int launch_gemm_bf16(const GemmParams& p, hipStream_t st) {
   const char* v = gemm_bf16_variant(p);
   if (!v) return DINOX_EUNSUPPORTED;
-  if (v[12] == '_') return launch_gemm_bf16_nt_glds(p, st);   // "gemm_bf16_nt_glds"
+  if (v[10] == 'n' && v[12] == '_') return launch_gemm_bf16_nt_glds(p, st);   // "gemm_bf16_nt_glds"
   const int tiles_m = (int)ceil_div(p.M, GB_BM), tiles_n = (int)ceil_div(p.N, GB_BN);
   const int64_t ntile = (int64_t)tiles_m * tiles_n;
   if (ntile > 0x7fffffff || p.batch > 65535) return DINOX_EUNSUPPORTED;
@@ -325,8 +455,9 @@ int launch_gemm_bf16(const GemmParams& p, hipStream_t st) {
   int splits = 1;
   const bool plain = (p.epilogue & ~DINOX_EPI_ACCUM) == 0 && p.out_dtype == DINOX_F32;
   if (plain) {
-    const int64_t want = 512, have = ntile * p.batch;
-    splits = (int)ceil_div(want, have);
+    // one resident round: 2 workgroups per CU x 256 CUs = 512 slots; a grid of 513..1023 would run two rounds
+    const int64_t slots = 512, have = ntile * p.batch;
+    splits = (int)(slots / have);
     const int64_t max_splits = ceil_div(p.K, 4 * GB_BK);  // at least 4 K-steps per workgroup
     if (splits > max_splits) splits = (int)max_splits;
     if (splits < 1) splits = 1;
@@ -349,6 +480,13 @@ int launch_gemm_bf16(const GemmParams& p, hipStream_t st) {
     if (e != hipSuccess) return fail((int)e, "gemm_bf16_tn: memset colsum: %s", hipGetErrorString(e));
   }
   dim3 grid((unsigned)ntile, (unsigned)(p.batch * splits));
+  if (v[12] == '_') {  // "gemm_bf16_tn_dma"
+    if (p.out_dtype == DINOX_F32)
+      hipLaunchKernelGGL((gemm_bf16_tn_dma<DINOX_F32>), grid, dim3(GB_THREADS), lds, st, p, tiles_m, tiles_n, splits, kps);
+    else
+      hipLaunchKernelGGL((gemm_bf16_tn_dma<DINOX_BF16>), grid, dim3(GB_THREADS), lds, st, p, tiles_m, tiles_n, splits, kps);
+    return check_launch("gemm_bf16_tn_dma");
+  }
   if (p.out_dtype == DINOX_F32)
     hipLaunchKernelGGL((gemm_bf16_tn<DINOX_F32>), grid, dim3(GB_THREADS), lds, st, p, tiles_m, tiles_n, splits, kps);
   else

@@ -90,7 +90,7 @@ def test_gemm_bf16_vs_exact(dx, tA, tB, M, N, K):
     out = ops.gemm(A.to(DEV), B.to(DEV), transA=bool(tA), transB=bool(tB), out_dtype=torch.float32)
     used, ops.TRACE_KERNELS = ops.TRACE_KERNELS, None
     # the MFMA-bf16 kernels must take every aligned NT / TN shape; only (0,1) falls to the fp32-MFMA kernel
-    want = {(0, 0): "gemm_bf16_nt_glds" if (K % 64 == 0 and N % 8 == 0) else "gemm_bf16_nt", (1, 1): "gemm_bf16_tn", (0, 1): "gemm_f32"}[(tA, tB)]
+    want = {(0, 0): "gemm_bf16_nt_glds" if (K % 64 == 0 and N % 8 == 0) else "gemm_bf16_nt", (1, 1): "gemm_bf16_tn_dma", (0, 1): "gemm_f32"}[(tA, tB)]
     assert used == [want], used
     close(out, ref, rtol=1e-5, atol=1e-5 * math.sqrt(K), what=f"bf16 gemm {tA}{tB} {M}x{N}x{K}")
     out_b = ops.gemm(A.to(DEV), B.to(DEV), transA=bool(tA), transB=bool(tB))

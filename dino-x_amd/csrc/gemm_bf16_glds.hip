@@ -16,13 +16,14 @@
 //   * epilogue variants are compile-time (no flag tests in the inner code) and GELU uses a 1.5e-7-accurate
 //     rational erf instead of erff.
 // Envelope: K % 64 == 0, N % 8 == 0, 16-B aligned operands/outputs; anything else takes gemm_bf16_nt.
+#include <cstdlib>
+
 #include "common.h"
 #include "gemm_common.h"
 
 namespace dinox {
 
-constexpr int GG_BM = 128, GG_BN = 128, GG_BK = 64, GG_THREADS = 256;
-constexpr int GG_TILE = 128 * 64 * 2;  // bytes per operand tile per stage
+constexpr int GG_BM = 128, GG_BN = 128, GG_THREADS = 256;
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_void;
@@ -34,8 +35,18 @@ __device__ __forceinline__ int gg_xcd_remap(int bid, int nwg) {
 
 enum { GG_PLAIN = 0, GG_GELU = 1, GG_DGELU = 2 };
 
-template <int OUT_DT, int ACT, bool RES>
-__global__ __launch_bounds__(GG_THREADS, 2) void gemm_bf16_nt_glds(GemmParams p, int tiles_m, int tiles_n) {
+// swizzle term of a tile row: 8 chunks/row (BK 64): (row>>1)&7 ; 4 chunks/row (BK 32): (row>>2)&3 -- each makes the
+// four 16-lane groups of ds_read_b128 hit 16 distinct 16-B bank slots.
+template <int CH>
+__device__ __forceinline__ int gg_swz(int row) { return CH == 8 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
+
+template <int OUT_DT, int ACT, bool RES, int GG_BK, int STAGES>
+__global__ __launch_bounds__(GG_THREADS, (GG_BK == 64 ? 2 : 3)) void gemm_bf16_nt_glds(GemmParams p, int tiles_m, int tiles_n) {
+  constexpr int GG_TILE = 128 * GG_BK * 2;        // bytes per operand tile per stage
+  constexpr int CH = GG_BK / 8;                   // 16-B chunks per tile row
+  constexpr int RPI = 64 / CH;                    // tile rows moved by one wave-instruction (1 KiB)
+  constexpr int NQ = 128 / RPI / 4;               // staging instructions per wave per operand
+  constexpr int ROWB = GG_BK * 2;                 // bytes per tile row
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -49,12 +60,12 @@ __global__ __launch_bounds__(GG_THREADS, 2) void gemm_bf16_nt_glds(GemmParams p,
 
   // Per-lane source pointers of this wave's 4 + 4 staging instructions (each moves 8 rows x 128 B).
   // LDS slot (row, c') of a tile receives logical chunk c = c' ^ ((row>>1)&7) of that row.
-  const bf16_t* asrc[4];
-  const bf16_t* bsrc[4];
+  const bf16_t* asrc[NQ];
+  const bf16_t* bsrc[NQ];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int row = (wv * 4 + q) * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((row >> 1) & 7);
+  for (int q = 0; q < NQ; ++q) {
+    const int row = (wv * NQ + q) * RPI + lane / CH;
+    const int c = (lane % CH) ^ gg_swz<CH>(row);
     int64_t gm = m0 + row, gn = n0 + row;
     gm = gm < p.M ? gm : p.M - 1;
     gn = gn < p.N ? gn : p.N - 1;
@@ -62,10 +73,10 @@ __global__ __launch_bounds__(GG_THREADS, 2) void gemm_bf16_nt_glds(GemmParams p,
     bsrc[q] = B + gn * p.ldb + c * 8;
   }
   auto stage = [&](int buf, int64_t k0) {
-    char* sa = smem + buf * 2 * GG_TILE + wv * 4096;
+    char* sa = smem + buf * 2 * GG_TILE + wv * (NQ * 1024);
     char* sb = sa + GG_TILE;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NQ; ++q) {
       __builtin_amdgcn_global_load_lds((gbl_void*)(asrc[q] + k0), (lds_void*)(sa + q * 1024), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((gbl_void*)(bsrc[q] + k0), (lds_void*)(sb + q * 1024), 16, 0, 0);
     }
@@ -80,114 +91,149 @@ __global__ __launch_bounds__(GG_THREADS, 2) void gemm_bf16_nt_glds(GemmParams p,
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const int nk = (int)(p.K / GG_BK);
-  stage(0, 0);
-  __syncthreads();
   const int frow = lane & 31, fh = lane >> 5;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) stage(cur ^ 1, (int64_t)(kt + 1) * GG_BK);
-    const char* sa = smem + cur * 2 * GG_TILE;
+  auto compute = [&](int buf) {
+    const char* sa = smem + buf * 2 * GG_TILE;
     const char* sb = sa + GG_TILE;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < GG_BK / 16; ++ks) {
       bf16x8 af[2], bfr[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int ra = wr * 64 + i * 32 + frow, rb = wc * 64 + i * 32 + frow;
         const int kc = 2 * ks + fh;
-        af[i] = *reinterpret_cast<const bf16x8*>(sa + ra * 128 + ((kc ^ ((ra >> 1) & 7)) << 4));
-        bfr[i] = *reinterpret_cast<const bf16x8*>(sb + rb * 128 + ((kc ^ ((rb >> 1) & 7)) << 4));
+        af[i] = *reinterpret_cast<const bf16x8*>(sa + ra * ROWB + ((kc ^ gg_swz<CH>(ra)) << 4));
+        bfr[i] = *reinterpret_cast<const bf16x8*>(sb + rb * ROWB + ((kc ^ gg_swz<CH>(rb)) << 4));
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
+  };
+  if (STAGES == 2) {
+    stage(0, 0);
     __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < nk) stage(cur ^ 1, (int64_t)(kt + 1) * GG_BK);
+      compute(cur);
+      __syncthreads();
+    }
+  } else {
+    // 3-stage ring, two K-steps of LDS-DMA in flight across the barrier: counted vmcnt + raw s_barrier (a
+    // __syncthreads() would drain the DMA queue).  Per step: wait for THIS step's tile (leave the next one in
+    // flight) -> barrier (every wave's pieces landed; every wave is done reading the slot refilled next) ->
+    // issue step kt+2 into the slot read at step kt-1 -> MFMAs.
+    stage(0, 0);
+    if (nk > 1) stage(1, GG_BK);
+    int buf = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NQ) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + 2 < nk) stage(buf == 0 ? 2 : buf - 1, (int64_t)(kt + 2) * GG_BK);
+      compute(buf);
+      buf = buf == 2 ? 0 : buf + 1;
+    }
+    __builtin_amdgcn_s_barrier();     // all waves done with the ring before it becomes the park area
   }
 
-  // ---- epilogue: park the wave's 64x64 block in LDS (row = 256 B, 16-B chunks XOR (row&15)), re-read by rows
-  char* park = smem + wv * 16384;
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-        const int n = j * 32 + frow;
-        *reinterpret_cast<float*>(park + row * 256 + ((((n >> 2) ^ (row & 15))) << 4) + (n & 3) * 4) = acc[i][j][e];
-      }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-
+  // ---- epilogue: park the wave's accumulator block in LDS (row = 256 B, 16-B chunks XOR (row&15)) and re-read it by
+  // rows.  With BK = 64 the four waves park 64 rows each at once (64 KiB = both stages); with BK = 32 the stages are
+  // 32 KiB, so each wave parks its two 32-row halves one after the other.
+  constexpr int PASSES = (STAGES * 2 * GG_TILE >= 65536) ? 1 : 2;
+  constexpr int PROWS = 64 / PASSES;
+  char* park = smem + wv * (PROWS * 256);
   const int c8 = lane & 7;
   const int64_t n = n0 + wc * 64 + c8 * 8;
-  if (n >= p.N) return;                                  // N % 8 == 0: a lane's 8 columns are all in or all out
+  const bool n_ok = n < p.N;                               // N % 8 == 0: a lane's 8 columns are all in or all out
   float bias[8];
 #pragma unroll
   for (int u = 0; u < 8; ++u) bias[u] = 0.f;
-  if (p.epilogue & DINOX_EPI_BIAS) {
+  if (n_ok && (p.epilogue & DINOX_EPI_BIAS)) {
     const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n), b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
     bias[0] = b0.x; bias[1] = b0.y; bias[2] = b0.z; bias[3] = b0.w;
     bias[4] = b1.x; bias[5] = b1.y; bias[6] = b1.z; bias[7] = b1.w;
   }
   const float alpha = p.alpha;
 #pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int row = it * 8 + (lane >> 3);
-    const int64_t m = m0 + wr * 64 + row;
-    const float4 lo = *reinterpret_cast<const float4*>(park + row * 256 + (((2 * c8) ^ (row & 15)) << 4));
-    const float4 hi = *reinterpret_cast<const float4*>(park + row * 256 + (((2 * c8 + 1) ^ (row & 15)) << 4));
-    if (m >= p.M) continue;
-    float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  for (int ps = 0; ps < PASSES; ++ps) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = v[u] * alpha + bias[u];
-    if (ACT == GG_GELU) {
-      if (p.aux) {
-        const int64_t ai = bz * p.M * p.ldaux + m * p.ldaux + n;
-        if (OUT_DT == DINOX_BF16) {
-          s16x8 pk;
+    for (int i = 0; i < 2; ++i) {
+      if (PASSES == 2 && i != ps) continue;
 #pragma unroll
-          for (int u = 0; u < 8; ++u) pk[u] = (short)f32_to_bf16(v[u]);
-          *reinterpret_cast<s16x8*>((bf16_t*)p.aux + ai) = pk;
-        } else {
-          *reinterpret_cast<float4*>((float*)p.aux + ai) = make_float4(v[0], v[1], v[2], v[3]);
-          *reinterpret_cast<float4*>((float*)p.aux + ai + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = (PASSES == 2 ? 0 : i * 32) + (e & 3) + 8 * (e >> 2) + 4 * fh;
+          const int nn = j * 32 + frow;
+          *reinterpret_cast<float*>(park + row * 256 + ((((nn >> 2) ^ (row & 15))) << 4) + (nn & 3) * 4) = acc[i][j][e];
         }
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = gelu_fast(v[u]);
     }
-    if (ACT == GG_DGELU) {
-      const int64_t ai = bz * p.M * p.ldaux + m * p.ldaux + n;
-      float x[8];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < PROWS / 8; ++it) {
+      const int row = it * 8 + (lane >> 3);
+      const int64_t m = m0 + wr * 64 + ps * PROWS + row;
+      const float4 lo = *reinterpret_cast<const float4*>(park + row * 256 + (((2 * c8) ^ (row & 15)) << 4));
+      const float4 hi = *reinterpret_cast<const float4*>(park + row * 256 + (((2 * c8 + 1) ^ (row & 15)) << 4));
+      if (m >= p.M || !n_ok) continue;
+      float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = v[u] * alpha + bias[u];
+      if (ACT == GG_GELU) {
+        if (p.aux) {
+          const int64_t ai = bz * p.M * p.ldaux + m * p.ldaux + n;
+          if (OUT_DT == DINOX_BF16) {
+            s16x8 pk;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) pk[u] = (short)f32_to_bf16(v[u]);
+            *reinterpret_cast<s16x8*>((bf16_t*)p.aux + ai) = pk;
+          } else {
+            *reinterpret_cast<float4*>((float*)p.aux + ai) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>((float*)p.aux + ai + 4) = make_float4(v[4], v[5], v[6], v[7]);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = gelu_fast(v[u]);
+      }
+      if (ACT == GG_DGELU) {
+        const int64_t ai = bz * p.M * p.ldaux + m * p.ldaux + n;
+        float x[8];
+        if (OUT_DT == DINOX_BF16) {
+          const s16x8 pk = *reinterpret_cast<const s16x8*>((const bf16_t*)p.aux + ai);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) x[u] = bf16_to_f32((bf16_t)pk[u]);
+        } else {
+          const float4 x0 = *reinterpret_cast<const float4*>((const float*)p.aux + ai), x1 = *reinterpret_cast<const float4*>((const float*)p.aux + ai + 4);
+          x[0] = x0.x; x[1] = x0.y; x[2] = x0.z; x[3] = x0.w; x[4] = x1.x; x[5] = x1.y; x[6] = x1.z; x[7] = x1.w;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] *= gelu_fast_grad(x[u]);
+      }
+      if (RES) {
+        const float* rp = p.residual + bz * p.M * p.ldr + m * p.ldr + n;
+        const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
+        v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
+        v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+      }
+      const int64_t ci = bz * p.strideC + m * p.ldc + n;
       if (OUT_DT == DINOX_BF16) {
-        const s16x8 pk = *reinterpret_cast<const s16x8*>((const bf16_t*)p.aux + ai);
+        s16x8 pk;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) x[u] = bf16_to_f32((bf16_t)pk[u]);
+        for (int u = 0; u < 8; ++u) pk[u] = (short)f32_to_bf16(v[u]);
+        *reinterpret_cast<s16x8*>((bf16_t*)p.C + ci) = pk;
       } else {
-        const float4 x0 = *reinterpret_cast<const float4*>((const float*)p.aux + ai), x1 = *reinterpret_cast<const float4*>((const float*)p.aux + ai + 4);
-        x[0] = x0.x; x[1] = x0.y; x[2] = x0.z; x[3] = x0.w; x[4] = x1.x; x[5] = x1.y; x[6] = x1.z; x[7] = x1.w;
+        *reinterpret_cast<float4*>((float*)p.C + ci) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>((float*)p.C + ci + 4) = make_float4(v[4], v[5], v[6], v[7]);
       }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] *= gelu_fast_grad(x[u]);
     }
-    if (RES) {
-      const float* rp = p.residual + bz * p.M * p.ldr + m * p.ldr + n;
-      const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
-      v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
-      v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
-    }
-    const int64_t ci = bz * p.strideC + m * p.ldc + n;
-    if (OUT_DT == DINOX_BF16) {
-      s16x8 pk;
-#pragma unroll
-      for (int u = 0; u < 8; ++u) pk[u] = (short)f32_to_bf16(v[u]);
-      *reinterpret_cast<s16x8*>((bf16_t*)p.C + ci) = pk;
-    } else {
-      *reinterpret_cast<float4*>((float*)p.C + ci) = make_float4(v[0], v[1], v[2], v[3]);
-      *reinterpret_cast<float4*>((float*)p.C + ci + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    if (PASSES == 2) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
   }
 }
@@ -196,7 +242,7 @@ static bool al16(const void* q) { return (((uintptr_t)q) & 15) == 0; }
 
 bool gemm_bf16_nt_glds_ok(const GemmParams& p) {
   if (p.in_dtype != DINOX_BF16 || p.transA || p.transB) return false;
-  if ((p.K % GG_BK) || (p.N & 7) || (p.lda & 7) || (p.ldb & 7) || (p.strideA & 7) || (p.strideB & 7)) return false;
+  if ((p.K % 64) || (p.N & 7) || (p.lda & 7) || (p.ldb & 7) || (p.strideA & 7) || (p.strideB & 7)) return false;
   if (!al16(p.A) || !al16(p.B) || !al16(p.C)) return false;
   const int esz = p.out_dtype == DINOX_BF16 ? 2 : 4;
   if ((p.ldc * esz) & 15 || (p.strideC * esz) & 15) return false;
@@ -213,10 +259,18 @@ int launch_gemm_bf16_nt_glds(const GemmParams& p, hipStream_t st) {
   const int64_t ntile = (int64_t)tiles_m * tiles_n;
   if (ntile > 0x7fffffff) return DINOX_EUNSUPPORTED;
   dim3 grid((unsigned)ntile, (unsigned)p.batch);
-  const size_t lds = 4 * GG_TILE;
+  static const int knob = getenv("DINOX_NT_BK") ? atoi(getenv("DINOX_NT_BK")) : 0;   // tuning knob: 64 | 32 (3-stage)
+  // measured (tools/gemm_bench.py): K <= 512 runs 6-12 % faster on the 3-stage BK=32 ring (3 workgroups/CU), longer K on
+  // the 2-stage BK=64 form
+  const int bk = knob ? knob : (p.K <= 512 ? 32 : 64);
+  const size_t lds = (bk == 64 ? 4 : 6) * (size_t)128 * bk * 2;
   const int act = (p.epilogue & DINOX_EPI_GELU) ? GG_GELU : (p.epilogue & DINOX_EPI_DGELU) ? GG_DGELU : GG_PLAIN;
   const bool res = (p.epilogue & DINOX_EPI_RESIDUAL) != 0;
-#define GG(OUT, ACT, RES) hipLaunchKernelGGL((gemm_bf16_nt_glds<OUT, ACT, RES>), grid, dim3(GG_THREADS), lds, st, p, tiles_m, tiles_n)
+#define GG(OUT, ACT, RES)                                                                                              \
+  do {                                                                                                                  \
+    if (bk == 32) hipLaunchKernelGGL((gemm_bf16_nt_glds<OUT, ACT, RES, 32, 3>), grid, dim3(GG_THREADS), lds, st, p, tiles_m, tiles_n); \
+    else hipLaunchKernelGGL((gemm_bf16_nt_glds<OUT, ACT, RES, 64, 2>), grid, dim3(GG_THREADS), lds, st, p, tiles_m, tiles_n);          \
+  } while (0)
 #define GG_ACT(OUT, RES)                                                                  \
   do {                                                                                    \
     if (act == GG_GELU) GG(OUT, GG_GELU, RES); else if (act == GG_DGELU) GG(OUT, GG_DGELU, RES); else GG(OUT, GG_PLAIN, RES); \

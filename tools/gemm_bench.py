@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of dinox_gemm on the hot-path shapes (ViT-S/16 bs256: M = 102912 tokens).
+Interleaved rounds in one process, HIP-event timing, random data (cdna_hip_programming.md rules 24/25)."""
+import os, sys, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "dino-x_amd")]
+import torch
+from dinox import ops
+
+M = int(os.environ.get("M", 102912))
+dev = "cuda"
+g = torch.Generator(device=dev).manual_seed(0)
+def rb(*s): return (torch.randn(*s, device=dev, generator=g) * 0.5).bfloat16()
+def rf(*s): return torch.randn(*s, device=dev, generator=g)
+
+cases = {}
+def case(name, fn, flops, bytes_):
+    cases[name] = (fn, flops, bytes_)
+
+D, H = 384, 1536
+x = rb(M, D); xh = rb(M, H); x3 = rb(M, 3 * D)
+wqkv, wproj, w1, w2 = rb(3 * D, D), rb(D, D), rb(H, D), rb(D, H)
+wqkvT, w1T, w2T = rb(D, 3 * D), rb(D, H), rb(H, D)
+bq, bd, bh = rf(3 * D), rf(D), rf(H)
+res = rf(M, D)
+pre = torch.empty(M, H, dtype=torch.bfloat16, device=dev)
+case("qkv   NT K384 N1152 bias        ", lambda: ops.gemm(x, wqkv, bias=bq), 2 * M * D * 3 * D, M * D * 2 + M * 3 * D * 2)
+case("proj  NT K384 N384  bias+res f32", lambda: ops.gemm(x, wproj, bias=bd, residual=res, out_dtype=torch.float32), 2 * M * D * D, M * D * 2 + 2 * M * D * 4)
+case("fc1   NT K384 N1536 bias+gelu+aux", lambda: ops.gemm(x, w1, bias=bh, gelu=True, aux=pre), 2 * M * D * H, M * D * 2 + 2 * M * H * 2)
+case("fc1t  NT K384 N1536 bias+gelu    ", lambda: ops.gemm(x, w1, bias=bh, gelu=True), 2 * M * D * H, M * D * 2 + M * H * 2)
+case("fc2   NT K1536 N384 bias+res f32", lambda: ops.gemm(xh, w2, bias=bd, residual=res, out_dtype=torch.float32), 2 * M * D * H, M * H * 2 + 2 * M * D * 4)
+case("dact  NT K384 N1536 dgelu        ", lambda: ops.gemm(x, w2T, dgelu=True, aux=pre), 2 * M * D * H, M * D * 2 + 2 * M * H * 2)
+case("dxn2  NT K1536 N384 plain        ", lambda: ops.gemm(xh, w1T), 2 * M * D * H, M * H * 2 + M * D * 2)
+case("dxn1  NT K1152 N384 plain        ", lambda: ops.gemm(x3, wqkvT), 2 * M * D * 3 * D, M * 3 * D * 2 + M * D * 2)
+db = torch.empty(H, device=dev)
+case("dW1   TN M1536 N384  (+db)       ", lambda: ops.gemm(xh, x, transA=True, transB=True, out_dtype=torch.float32, colsum_out=db), 2 * M * D * H, M * H * 2 + M * D * 2)
+dbq = torch.empty(3 * D, device=dev)
+case("dWqkv TN M1152 N384  (+db)       ", lambda: ops.gemm(x3, x, transA=True, transB=True, out_dtype=torch.float32, colsum_out=dbq), 2 * M * D * 3 * D, M * 3 * D * 2 + M * D * 2)
+dbd = torch.empty(D, device=dev)
+case("dW2   TN M384 N1536  (+db)       ", lambda: ops.gemm(x, xh, transA=True, transB=True, out_dtype=torch.float32, colsum_out=dbd), 2 * M * D * H, M * H * 2 + M * D * 2)
+case("dWp   TN M384 N384   (+db)       ", lambda: ops.gemm(x, x, transA=True, transB=True, out_dtype=torch.float32, colsum_out=dbd), 2 * M * D * D, 2 * M * D * 2)
+
+sel = os.environ.get("CASES")
+names = [n for n in cases if not sel or any(s in n for s in sel.split(","))]
+for n in names:
+    for _ in range(3): cases[n][0]()
+torch.cuda.synchronize()
+R = int(os.environ.get("ROUNDS", 10))
+times = {n: [] for n in names}
+for r in range(R):
+    for n in names:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); cases[n][0](); e1.record()
+        times[n].append((e0, e1))
+torch.cuda.synchronize()
+for n in names:
+    ts = sorted(a.elapsed_time(b) * 1e3 for a, b in times[n])
+    med = ts[len(ts) // 2]
+    fn, fl, by = cases[n]
+    print(f"{n}  med {med:8.1f} us  min {ts[0]:8.1f} us   {fl / med / 1e6:7.1f} TFLOP/s   {by / med / 1e6:6.2f} TB/s alg")

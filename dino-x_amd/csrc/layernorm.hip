@@ -107,9 +107,9 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_generic(const float* __rest
 template <int DY_DT, int NV>
 __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const void* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ w, const float* __restrict__ mean,
-                                                            const float* __restrict__ rstd, float* __restrict__ dx,
+                                                            const float* __restrict__ rstd, float* dx,
                                                             void* __restrict__ dx_lowp, float* __restrict__ ws,
-                                                            int64_t rows, int dim, int accumulate) {
+                                                            int64_t rows, int dim, const float* dx_add) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int64_t wave = (int64_t)blockIdx.x * (LN_THREADS / 64) + wv;
@@ -159,8 +159,8 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const void* __restri
         o.z = rs * (g[j].z - m1 - xh[j].z * m2);
         o.w = rs * (g[j].w - m1 - xh[j].w * m2);
         float4* dst = reinterpret_cast<float4*>(dx + r * dim) + c;
-        if (accumulate) {
-          const float4 p = *dst;
+        if (dx_add) {
+          const float4 p = reinterpret_cast<const float4*>(dx_add + r * dim)[c];
           o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
         }
         *dst = o;
@@ -191,9 +191,9 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const void* __restri
 template <int DY_DT>
 __global__ __launch_bounds__(LN_THREADS) void ln_bwd_generic(const void* __restrict__ dy, const float* __restrict__ x,
                                                              const float* __restrict__ w, const float* __restrict__ mean,
-                                                             const float* __restrict__ rstd, float* __restrict__ dx,
+                                                             const float* __restrict__ rstd, float* dx,
                                                              void* __restrict__ dx_lowp, float* __restrict__ ws,
-                                                             int64_t rows, int dim, int accumulate) {
+                                                             int64_t rows, int dim, const float* dx_add) {
   // Generic fallback: one wave per row for dx; dw/db partials via LDS atomics per block.
   extern __shared__ __attribute__((aligned(16))) float lds[];
   for (int c = threadIdx.x; c < 2 * dim; c += LN_THREADS) lds[c] = 0.f;
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_generic(const void* __restr
     for (int c = lane; c < dim; c += 64) {
       const float d = elem<DY_DT>::ld(dy, r * dim + c), xh = (x[r * dim + c] - mu) * rs;
       float o = rs * (d * w[c] - m1 - xh * m2);
-      if (accumulate) o += dx[r * dim + c];
+      if (dx_add) o += dx_add[r * dim + c];
       dx[r * dim + c] = o;
       if (dx_lowp) ((bf16_t*)dx_lowp)[r * dim + c] = f32_to_bf16(o);
     }
@@ -286,8 +286,8 @@ extern "C" int64_t dinox_layernorm_bwd_ws_bytes(int64_t rows, int dim) {
 }
 
 extern "C" int dinox_layernorm_bwd(const void* dy, const float* x, const float* w, const float* mean, const float* rstd,
-                                   float* dx, void* dx_lowp, float* dw, float* db, void* ws, int64_t rows, int dim,
-                                   int dy_dtype, int accumulate_dx, void* stream) {
+                                   float* dx, const float* dx_add, void* dx_lowp, float* dw, float* db, void* ws,
+                                   int64_t rows, int dim, int dy_dtype, void* stream) {
   DX_REQUIRE(dy && x && w && mean && rstd && dx && dw && db && ws, DINOX_EINVAL, "layernorm_bwd: null pointer");
   DX_REQUIRE(rows > 0 && dim > 0, DINOX_EINVAL, "layernorm_bwd: rows=%lld dim=%d", (long long)rows, dim);
   DX_REQUIRE(dy_dtype == DINOX_F32 || dy_dtype == DINOX_BF16, DINOX_EINVAL, "layernorm_bwd: dtype %d", dy_dtype);
@@ -296,7 +296,7 @@ extern "C" int dinox_layernorm_bwd(const void* dy, const float* x, const float* 
   const size_t lds = (size_t)(LN_THREADS / 64) * 2 * dim * sizeof(float);
   const bool fast = (dim % 4 == 0) && dim <= 256 * LN_MAXV && lds <= 64 * 1024;
   float* wsf = (float*)ws;
-#define LN_BWD(DT, NV) hipLaunchKernelGGL((ln_bwd_kernel<DT, NV>), dim3(parts), dim3(LN_THREADS), lds, st, dy, x, w, mean, rstd, dx, dx_lowp, wsf, rows, dim, accumulate_dx)
+#define LN_BWD(DT, NV) hipLaunchKernelGGL((ln_bwd_kernel<DT, NV>), dim3(parts), dim3(LN_THREADS), lds, st, dy, x, w, mean, rstd, dx, dx_lowp, wsf, rows, dim, dx_add)
   if (fast) {
     const int nv = (int)ceil_div(dim / 4, 64);
     if (dy_dtype == DINOX_F32) {
@@ -308,9 +308,9 @@ extern "C" int dinox_layernorm_bwd(const void* dy, const float* x, const float* 
     const size_t l2 = (size_t)2 * dim * sizeof(float);
     DX_REQUIRE(l2 <= 64 * 1024, DINOX_EUNSUPPORTED, "layernorm_bwd: dim %d too large", dim);
     if (dy_dtype == DINOX_F32)
-      hipLaunchKernelGGL((ln_bwd_generic<DINOX_F32>), dim3(parts), dim3(LN_THREADS), l2, st, dy, x, w, mean, rstd, dx, dx_lowp, wsf, rows, dim, accumulate_dx);
+      hipLaunchKernelGGL((ln_bwd_generic<DINOX_F32>), dim3(parts), dim3(LN_THREADS), l2, st, dy, x, w, mean, rstd, dx, dx_lowp, wsf, rows, dim, dx_add);
     else
-      hipLaunchKernelGGL((ln_bwd_generic<DINOX_BF16>), dim3(parts), dim3(LN_THREADS), l2, st, dy, x, w, mean, rstd, dx, dx_lowp, wsf, rows, dim, accumulate_dx);
+      hipLaunchKernelGGL((ln_bwd_generic<DINOX_BF16>), dim3(parts), dim3(LN_THREADS), l2, st, dy, x, w, mean, rstd, dx, dx_lowp, wsf, rows, dim, dx_add);
   }
 #undef LN_BWD
   int rc = check_launch("layernorm_bwd");

@@ -255,19 +255,21 @@ def layernorm_fwd(x: Tensor, w: Tensor, b: Tensor, out_dtype: torch.dtype, eps: 
 
 
 def layernorm_bwd(dy: Tensor, x: Tensor, w: Tensor, mean: Tensor, rstd: Tensor, dx: Optional[Tensor] = None,
-                  accumulate=False, want_lowp=False):
+                  dx_add: Optional[Tensor] = None, want_lowp=False):
+    """dx = (dx_add or 0) + LN'(dy); returns (dx, dw, db, bf16 copy of dx or None).  dx may alias dx_add."""
     dy, x = _c(dy), _c(x)
     D = x.shape[-1]
     rows = x.numel() // D
     if dx is None:
-        assert not accumulate
         dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    if dx_add is not None:
+        assert dx_add.is_contiguous() and dx_add.dtype == torch.float32 and dx_add.numel() == x.numel()
     dw = torch.empty(D, dtype=torch.float32, device=x.device)
     db = torch.empty(D, dtype=torch.float32, device=x.device)
     lowp = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if want_lowp else None
     ws = torch.empty(lib.dinox_layernorm_bwd_ws_bytes(rows, D), dtype=torch.uint8, device=x.device)
-    check(lib.dinox_layernorm_bwd(_p(dy), _p(x), _p(w), _p(mean), _p(rstd), _p(dx), _p(lowp), _p(dw), _p(db), _p(ws), rows, D,
-                                  _code(dy.dtype), int(accumulate), _stream()), "dinox_layernorm_bwd")
+    check(lib.dinox_layernorm_bwd(_p(dy), _p(x), _p(w), _p(mean), _p(rstd), _p(dx), _p(dx_add), _p(lowp), _p(dw), _p(db), _p(ws),
+                                  rows, D, _code(dy.dtype), _stream()), "dinox_layernorm_bwd")
     return dx, dw, db, lowp
 
 
@@ -302,13 +304,121 @@ class LayerNormFn(torch.autograd.Function):
     def forward(ctx, x, w, b, out_dtype, eps):
         y, mean, rstd = layernorm_fwd(x, w, b, out_dtype, eps)
         ctx.save_for_backward(x, w, mean, rstd)
+        ctx.mode_bf16 = current_dtype() == torch.bfloat16
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w, mean, rstd = ctx.saved_tensors
-        dx, dw, db, _ = layernorm_bwd(dy, x, w, mean, rstd)
+        dx, dw, db, lowp = layernorm_bwd(dy, x, w, mean, rstd, want_lowp=ctx.mode_bf16)
+        if lowp is not None:
+            lowp_cache.put(dx, lowp)
         return dx, dw, db, None, None
+
+
+class _LowpCache:
+    """bf16 copies of residual-stream gradients, handed from the kernel that produced the fp32 gradient
+    (LayerNorm backward writes both) to the next backward node, which needs the bf16 form as a GEMM operand."""
+
+    def __init__(self) -> None:
+        self.key = None
+        self.val = None
+
+    def put(self, t: Tensor, lowp: Tensor) -> None:
+        self.key, self.val = (t.data_ptr(), t._version, tuple(t.shape)), lowp
+
+    def take(self, t: Tensor) -> Optional[Tensor]:
+        if self.key == (t.data_ptr(), t._version, tuple(t.shape)):
+            v, self.key, self.val = self.val, None, None
+            return v
+        return None
+
+
+lowp_cache = _LowpCache()
+
+
+def grad_operand(g: Tensor, dt: torch.dtype) -> Tensor:
+    """A residual-stream gradient as a GEMM operand of the current mode (cached bf16 copy if one was emitted)."""
+    if dt == torch.float32:
+        return _c(g) if g.dtype == torch.float32 else g.float()
+    if g.dtype == torch.bfloat16:
+        return _c(g)
+    hit = lowp_cache.take(g)
+    return hit if hit is not None else cast_bf16(g)
+
+
+class BlockFn(torch.autograd.Function):
+    """One pre-norm transformer block as a single autograd node (reference zoo/arch.py:94-97 with
+    Attention :43-54 and Mlp :75-76 inlined):  x1 = x0 + proj(attn(norm1(x0)));  x2 = x1 + fc2(gelu(fc1(norm2(x1)))).
+
+    13 kernel launches forward, 15 backward, no torch elementwise kernels: residual adds live in GEMM
+    epilogues, the skip-connection gradient add and the bf16 cast of the residual gradient live in the
+    LayerNorm backward kernel, bias gradients ride along the dW products."""
+
+    @staticmethod
+    def forward(ctx, x0, n1w, n1b, wqkv, bqkv, wproj, bproj, n2w, n2b, w1, b1, w2, b2, heads, eps):
+        _need_cuda(x0, wqkv)
+        dt = current_dtype()
+        x0 = _c(x0 if x0.dtype == torch.float32 else x0.float())
+        V, N, D = x0.shape
+        M = V * N
+        train = any(ctx.needs_input_grad)
+        xn1, mean1, rstd1 = layernorm_fwd(x0, n1w, n1b, dt, eps)
+        qkv = gemm(xn1.view(M, D), weight_operand(wqkv, dt), bias=bqkv, out_dtype=dt)
+        o, lse = attention_fwd(qkv.view(V, N, 3 * D), heads)
+        x1 = gemm(o.view(M, D), weight_operand(wproj, dt), bias=bproj, residual=x0.view(M, D), out_dtype=torch.float32)
+        xn2, mean2, rstd2 = layernorm_fwd(x1, n2w, n2b, dt, eps)
+        pre = torch.empty((M, w1.shape[0]), dtype=dt, device=x0.device) if train else None
+        act = gemm(xn2, weight_operand(w1, dt), bias=b1, gelu=True, aux=pre, out_dtype=dt)
+        x2 = gemm(act, weight_operand(w2, dt), bias=b2, residual=x1, out_dtype=torch.float32)
+        if train:
+            ctx.save_for_backward(x0, x1, xn1, xn2, qkv, o, lse, pre, act, mean1, rstd1, mean2, rstd2, n1w, n2w, wqkv, wproj, w1, w2)
+            ctx.dt, ctx.heads, ctx.shape = dt, heads, (V, N, D)
+            ctx.has_bias = (bqkv is not None, bproj is not None, b1 is not None, b2 is not None)
+        return x2.view(V, N, D)
+
+    @staticmethod
+    def backward(ctx, g):
+        x0, x1, xn1, xn2, qkv, o, lse, pre, act, mean1, rstd1, mean2, rstd2, n1w, n2w, wqkv, wproj, w1, w2 = ctx.saved_tensors
+        dt, heads = ctx.dt, ctx.heads
+        V, N, D = ctx.shape
+        M = V * N
+        dev = g.device
+        g = _c(g if g.dtype == torch.float32 else g.float())
+        bf = dt == torch.bfloat16
+        f32 = lambda n: torch.empty(n, dtype=torch.float32, device=dev)
+
+        def wt(w):      # W^T operand for dX = dY . W
+            return (w.detach(), dict(transB=True)) if not bf else (weight_operand(w, dt, transposed=True), {})
+
+        g_op = grad_operand(g, dt).view(M, D)
+        # ---- MLP: x2 = x1 + fc2(gelu(fc1(xn2)))
+        b, kw = wt(w2)
+        dpre = gemm(g_op, b, dgelu=True, aux=pre, out_dtype=dt, **kw)
+        db2 = f32(w2.shape[0]) if ctx.has_bias[3] else None
+        dw2 = gemm(g_op, act, transA=True, transB=True, out_dtype=torch.float32, colsum_out=db2)
+        b, kw = wt(w1)
+        dxn2 = gemm(dpre, b, out_dtype=dt, **kw)
+        db1 = f32(w1.shape[0]) if ctx.has_bias[2] else None
+        dw1 = gemm(dpre, xn2.view(M, D), transA=True, transB=True, out_dtype=torch.float32, colsum_out=db1)
+        del dpre
+        g1, dn2w, dn2b, g1_lp = layernorm_bwd(dxn2, x1, n2w, mean2, rstd2, dx_add=g.view(M, D), want_lowp=bf)   # g1 = g + LN2'(.)
+        g1_op = g1_lp if bf else g1
+        # ---- attention: x1 = x0 + proj(attn(qkv(xn1)))
+        b, kw = wt(wproj)
+        do = gemm(g1_op, b, out_dtype=dt, **kw)
+        dbp = f32(wproj.shape[0]) if ctx.has_bias[1] else None
+        dwp = gemm(g1_op, o.view(M, D), transA=True, transB=True, out_dtype=torch.float32, colsum_out=dbp)
+        dqkv = attention_bwd(do.view(V, N, D), qkv.view(V, N, 3 * D), o, lse, heads).view(M, 3 * D)
+        b, kw = wt(wqkv)
+        dxn1 = gemm(dqkv, b, out_dtype=dt, **kw)
+        dbq = f32(wqkv.shape[0]) if ctx.has_bias[0] else None
+        dwq = gemm(dqkv, xn1.view(M, D), transA=True, transB=True, out_dtype=torch.float32, colsum_out=dbq)
+        g0, dn1w, dn1b, g0_lp = layernorm_bwd(dxn1, x0, n1w, mean1, rstd1, dx=g1, dx_add=g1, want_lowp=bf)      # in place on our own g1
+        g0 = g0.view(V, N, D)
+        if g0_lp is not None:
+            lowp_cache.put(g0, g0_lp.view(V, N, D))
+        return g0, dn1w, dn1b, dwq, dbq, dwp, dbp, dn2w, dn2b, dw1, db1, dw2, db2, None, None
 
 
 class LinearFn(torch.autograd.Function):

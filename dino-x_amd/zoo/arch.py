@@ -104,7 +104,19 @@ class TransformerBlock(nn.Module):
         self.norm2 = LayerNorm(dim)
         self.mlp = Mlp(dim, mlp_ratio)
 
+    def _fusable(self) -> bool:
+        a, m = self.attn, self.mlp
+        return (type(self.norm1) is LayerNorm and type(self.norm2) is LayerNorm and type(a) is Attention and type(m) is Mlp
+                and type(a.qkv) is Linear and type(a.proj) is Linear and type(m.fc1) is Linear and type(m.fc2) is Linear
+                and self.norm1.eps == self.norm2.eps)
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self._fusable():      # the whole block as ONE autograd node (ops.BlockFn); weights are read from the sub-modules
+            a, m = self.attn, self.mlp
+            return ops.BlockFn.apply(x, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias,
+                                     self.norm2.weight, self.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias,
+                                     a.num_heads, self.norm1.eps)
+        # a sub-module was replaced (e.g. LoRA-wrapped): compose the per-op nodes instead
         x = self.attn(self.norm1(x), residual=x)
         x = self.mlp(self.norm2(x), residual=x)
         return x

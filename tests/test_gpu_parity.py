@@ -153,7 +153,10 @@ def test_layernorm(dx, rows, dim):
     yb, _, _ = ops.layernorm_fwd(X, W, Bb, torch.bfloat16)
     assert rel_l2(yb.float(), y_ref) < 4e-3
     base = torch.ones(rows, dim, device=DEV)
-    dxo, dw, db, lowp = ops.layernorm_bwd(DY, X, W, mean, rs, dx=base.clone(), accumulate=True, want_lowp=True)
+    dxo, dw, db, lowp = ops.layernorm_bwd(DY, X, W, mean, rs, dx_add=base, want_lowp=True)        # out of place
+    inpl = base.clone()
+    ops.layernorm_bwd(DY, X, W, mean, rs, dx=inpl, dx_add=inpl)                                   # in place
+    assert torch.equal(inpl, dxo)
     close(dxo, dx_ref + 1.0, 2e-5, 2e-5, "ln dx (accumulate)")
     close(dw, dw_ref, 2e-5, 1e-4, "ln dw")
     close(db, db_ref, 2e-5, 1e-4, "ln db")
@@ -354,6 +357,44 @@ def test_vit_tiny_golden(dx, mode):
         bad = [n for n in [str(s) for s in g["param_order"]]
                if rel_l2(P[n].grad, g[f"grad/{n}"]) > 0.08 and np.abs(g[f"grad/{n}"]).max() > 1e-6]
         assert not bad, bad
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_block_fused_node_matches_composed_ops(dx, mode):
+    """TransformerBlock takes the single-node BlockFn path when its leaves are the stock module types and the
+    per-op composition otherwise (e.g. LoRA-wrapped leaves); both must agree (and both are HIP-only)."""
+    ops, arch = dx
+
+    class Wrapped(arch.Linear):          # same math, different type -> forces the composed path
+        pass
+
+    torch.manual_seed(4)
+    blk = arch.TransformerBlock(128, 2).to(DEV)
+    with torch.no_grad():
+        for p_ in blk.parameters():
+            if p_.ndim == 1:
+                p_.add_(0.05 * torch.randn_like(p_))
+    blk2 = arch.TransformerBlock(128, 2).to(DEV)
+    blk2.load_state_dict(blk.state_dict())
+    w = Wrapped(128, 512).to(DEV)
+    w.load_state_dict(blk.mlp.fc1.state_dict())
+    blk2.mlp.fc1 = w
+    assert blk._fusable() and not blk2._fusable()
+    x = torch.randn(3, 37, 128, device=DEV)
+    dy = torch.randn(3, 37, 128, device=DEV)
+    dt = torch.float32 if mode == "fp32" else torch.bfloat16
+    outs = []
+    for b in (blk, blk2):
+        xi = x.clone().requires_grad_(True)
+        with ops.compute_dtype(dt):
+            y = b(xi)
+            y.backward(dy)
+        outs.append((y.detach(), xi.grad, {n: p_.grad for n, p_ in b.named_parameters()}))
+    tol = 1e-5 if mode == "fp32" else 2e-2
+    assert rel_l2(outs[0][0], outs[1][0]) < tol
+    assert rel_l2(outs[0][1], outs[1][1]) < tol
+    for n in outs[0][2]:
+        assert rel_l2(outs[0][2][n], outs[1][2][n]) < tol, n
 
 
 def test_vit_plain_golden_no_registers(dx):

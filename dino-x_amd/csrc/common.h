@@ -73,6 +73,13 @@ __device__ __forceinline__ float gelu_fast(float x) {
   float e;
   return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f, e));
 }
+// gelu and its derivative from ONE erf/exp evaluation
+__device__ __forceinline__ void gelu_fast_both(float x, float& y, float& dy) {
+  float e;
+  const float h = 0.5f * (1.0f + erf_as(x * 0.70710678118654752f, e));
+  y = x * h;
+  dy = h + x * e * 0.39894228040143268f;
+}
 __device__ __forceinline__ float gelu_fast_grad(float x) {
   float e;  // e = exp(-x^2/2)
   const float er = erf_as(x * 0.70710678118654752f, e);

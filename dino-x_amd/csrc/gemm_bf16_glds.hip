@@ -185,20 +185,35 @@ __global__ __launch_bounds__(GG_THREADS, (GG_BK == 64 ? 2 : 3)) void gemm_bf16_n
 #pragma unroll
       for (int u = 0; u < 8; ++u) v[u] = v[u] * alpha + bias[u];
       if (ACT == GG_GELU) {
+        const bool ag = (p.epilogue & DINOX_EPI_AUXGRAD) != 0;          // workgroup-uniform
+        float a[8];
+        if (ag) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            float y, d;
+            gelu_fast_both(v[u], y, d);
+            a[u] = d;
+            v[u] = y;
+          }
+        } else {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            a[u] = v[u];
+            v[u] = gelu_fast(v[u]);
+          }
+        }
         if (p.aux) {
           const int64_t ai = bz * p.M * p.ldaux + m * p.ldaux + n;
           if (OUT_DT == DINOX_BF16) {
             s16x8 pk;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) pk[u] = (short)f32_to_bf16(v[u]);
+            for (int u = 0; u < 8; ++u) pk[u] = (short)f32_to_bf16(a[u]);
             *reinterpret_cast<s16x8*>((bf16_t*)p.aux + ai) = pk;
           } else {
-            *reinterpret_cast<float4*>((float*)p.aux + ai) = make_float4(v[0], v[1], v[2], v[3]);
-            *reinterpret_cast<float4*>((float*)p.aux + ai + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            *reinterpret_cast<float4*>((float*)p.aux + ai) = make_float4(a[0], a[1], a[2], a[3]);
+            *reinterpret_cast<float4*>((float*)p.aux + ai + 4) = make_float4(a[4], a[5], a[6], a[7]);
           }
         }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = gelu_fast(v[u]);
       }
       if (ACT == GG_DGELU) {
         const int64_t ai = bz * p.M * p.ldaux + m * p.ldaux + n;
@@ -211,8 +226,13 @@ __global__ __launch_bounds__(GG_THREADS, (GG_BK == 64 ? 2 : 3)) void gemm_bf16_n
           const float4 x0 = *reinterpret_cast<const float4*>((const float*)p.aux + ai), x1 = *reinterpret_cast<const float4*>((const float*)p.aux + ai + 4);
           x[0] = x0.x; x[1] = x0.y; x[2] = x0.z; x[3] = x0.w; x[4] = x1.x; x[5] = x1.y; x[6] = x1.z; x[7] = x1.w;
         }
+        if (p.epilogue & DINOX_EPI_AUXGRAD) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] *= gelu_fast_grad(x[u]);
+          for (int u = 0; u < 8; ++u) v[u] *= x[u];
+        } else {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] *= gelu_fast_grad(x[u]);
+        }
       }
       if (RES) {
         const float* rp = p.residual + bz * p.M * p.ldr + m * p.ldr + n;

@@ -28,10 +28,13 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int64_t bz, 
                                                float bias) {
   float v = acc * p.alpha + bias;
   if (p.epilogue & DINOX_EPI_GELU) {
-    if (p.aux) elem<OUT_DT>::st(p.aux, bz * p.M * p.ldaux + m * p.ldaux + n, v);
+    if (p.aux) elem<OUT_DT>::st(p.aux, bz * p.M * p.ldaux + m * p.ldaux + n, (p.epilogue & DINOX_EPI_AUXGRAD) ? gelu_erf_grad(v) : v);
     v = gelu_erf(v);
   }
-  if (p.epilogue & DINOX_EPI_DGELU) v *= gelu_erf_grad(elem<OUT_DT>::ld(p.aux, bz * p.M * p.ldaux + m * p.ldaux + n));
+  if (p.epilogue & DINOX_EPI_DGELU) {
+    const float a = elem<OUT_DT>::ld(p.aux, bz * p.M * p.ldaux + m * p.ldaux + n);
+    v *= (p.epilogue & DINOX_EPI_AUXGRAD) ? a : gelu_erf_grad(a);
+  }
   if (p.epilogue & DINOX_EPI_RESIDUAL) v += p.residual[bz * p.M * p.ldr + m * p.ldr + n];
   const int64_t ci = bz * p.strideC + m * p.ldc + n;
   if (p.epilogue & DINOX_EPI_ACCUM) v += ((const float*)p.C)[ci];

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdinox_hip.so")
 
 F32, BF16 = 0, 1
-EPI_BIAS, EPI_GELU, EPI_DGELU, EPI_RESIDUAL, EPI_ACCUM = 1, 2, 4, 8, 16
+EPI_BIAS, EPI_GELU, EPI_DGELU, EPI_RESIDUAL, EPI_ACCUM, EPI_AUXGRAD = 1, 2, 4, 8, 16, 32
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 

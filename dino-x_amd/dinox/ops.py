@@ -19,7 +19,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import BF16, EPI_ACCUM, EPI_BIAS, EPI_DGELU, EPI_GELU, EPI_RESIDUAL, F32, GemmArgs, check, lib
+from ._lib import BF16, EPI_ACCUM, EPI_AUXGRAD, EPI_BIAS, EPI_DGELU, EPI_GELU, EPI_RESIDUAL, F32, GemmArgs, check, lib
 
 Tensor = torch.Tensor
 _OVERRIDE: list = []
@@ -122,7 +122,7 @@ TRACE_KERNELS: Optional[list] = None      # tests set this to a list to learn wh
 def gemm(A: Tensor, B: Tensor, *, transA=False, transB=False, out: Optional[Tensor] = None,
          out_dtype: Optional[torch.dtype] = None, bias: Optional[Tensor] = None, gelu=False, aux: Optional[Tensor] = None,
          dgelu=False, residual: Optional[Tensor] = None, accumulate=False, alpha: float = 1.0,
-         colsum_out: Optional[Tensor] = None) -> Tensor:
+         colsum_out: Optional[Tensor] = None, auxgrad=False) -> Tensor:
     """C = epilogue(alpha * op(A) op(B)^T); A: [M,K] (or [K,M] if transA), B: [N,K] (or [K,N] if transB).
     3-D operands are batched over dim 0 (B may be 2-D = shared)."""
     _need_cuda(A, B)
@@ -158,6 +158,8 @@ def gemm(A: Tensor, B: Tensor, *, transA=False, transB=False, out: Optional[Tens
         assert residual.dtype == torch.float32 and residual.is_contiguous() and residual.numel() == batch * M * N
     if accumulate:
         epi |= EPI_ACCUM
+    if auxgrad:
+        epi |= EPI_AUXGRAD
     if colsum_out is not None:
         assert transA and not batched and colsum_out.dtype == torch.float32 and colsum_out.numel() == M and colsum_out.is_contiguous()
     g = GemmArgs(
@@ -369,7 +371,7 @@ class BlockFn(torch.autograd.Function):
         x1 = gemm(o.view(M, D), weight_operand(wproj, dt), bias=bproj, residual=x0.view(M, D), out_dtype=torch.float32)
         xn2, mean2, rstd2 = layernorm_fwd(x1, n2w, n2b, dt, eps)
         pre = torch.empty((M, w1.shape[0]), dtype=dt, device=x0.device) if train else None
-        act = gemm(xn2, weight_operand(w1, dt), bias=b1, gelu=True, aux=pre, out_dtype=dt)
+        act = gemm(xn2, weight_operand(w1, dt), bias=b1, gelu=True, aux=pre, auxgrad=True, out_dtype=dt)   # pre := gelu'(fc1 out)
         x2 = gemm(act, weight_operand(w2, dt), bias=b2, residual=x1, out_dtype=torch.float32)
         if train:
             ctx.save_for_backward(x0, x1, xn1, xn2, qkv, o, lse, pre, act, mean1, rstd1, mean2, rstd2, n1w, n2w, wqkv, wproj, w1, w2)
@@ -394,7 +396,7 @@ class BlockFn(torch.autograd.Function):
         g_op = grad_operand(g, dt).view(M, D)
         # ---- MLP: x2 = x1 + fc2(gelu(fc1(xn2)))
         b, kw = wt(w2)
-        dpre = gemm(g_op, b, dgelu=True, aux=pre, out_dtype=dt, **kw)
+        dpre = gemm(g_op, b, dgelu=True, aux=pre, auxgrad=True, out_dtype=dt, **kw)
         db2 = f32(w2.shape[0]) if ctx.has_bias[3] else None
         dw2 = gemm(g_op, act, transA=True, transB=True, out_dtype=torch.float32, colsum_out=db2)
         b, kw = wt(w1)
@@ -474,7 +476,7 @@ class MlpFn(torch.autograd.Function):
         x2 = xm.reshape(-1, xm.shape[-1])
         M, H = x2.shape[0], w1.shape[0]
         pre = torch.empty((M, H), dtype=dt, device=x.device) if any(ctx.needs_input_grad[:5]) else None
-        act = gemm(x2, weight_operand(w1, dt), bias=b1, gelu=True, aux=pre, out_dtype=dt)
+        act = gemm(x2, weight_operand(w1, dt), bias=b1, gelu=True, aux=pre, auxgrad=True, out_dtype=dt)
         odt = torch.float32 if residual is not None else (out_dtype or dt)
         y = gemm(act, weight_operand(w2, dt), bias=b2, residual=None if residual is None else _c(residual).reshape(M, w2.shape[0]),
                  out_dtype=odt)
@@ -489,9 +491,9 @@ class MlpFn(torch.autograd.Function):
         dt = ctx.dt
         dy2 = to_mode(dy.reshape(-1, w2.shape[0]), dt)
         if dt == torch.float32:
-            dpre = gemm(dy2, w2.detach(), transB=True, dgelu=True, aux=pre, out_dtype=dt)
+            dpre = gemm(dy2, w2.detach(), transB=True, dgelu=True, aux=pre, auxgrad=True, out_dtype=dt)
         else:
-            dpre = gemm(dy2, weight_operand(w2, dt, transposed=True), dgelu=True, aux=pre, out_dtype=dt)
+            dpre = gemm(dy2, weight_operand(w2, dt, transposed=True), dgelu=True, aux=pre, auxgrad=True, out_dtype=dt)
         db2 = torch.empty(w2.shape[0], dtype=torch.float32, device=dy2.device) if ctx.has_b2 else None
         dw2 = gemm(dy2, act, transA=True, transB=True, out_dtype=torch.float32, colsum_out=db2)
         dx = None

@@ -70,6 +70,9 @@ int dinox_device_ok(void);
 #define DINOX_EPI_DGELU 4
 #define DINOX_EPI_RESIDUAL 8
 #define DINOX_EPI_ACCUM 16
+#define DINOX_EPI_AUXGRAD 32   /* modifies GELU: aux receives gelu_erf'(pre-activation) instead of the pre-activation;
+                                * modifies DGELU: acc *= aux (aux already holds the derivative).  Saves the
+                                * transcendental work of the backward epilogue: forward evaluates erf/exp once for both. */
 
 typedef struct dinox_gemm_args {
   const void* A;

@@ -1,0 +1,183 @@
+"""CPU checks of the scripts/phase5_big_run.py drop-in: flag surface, config dataclasses, importable names, host data
+pipeline, checkpoint payload (reference keys; optimiser state in torch.optim.AdamW format).  The flag list below is the
+reference's argparse surface (scripts/phase5_big_run.py:1238-1331) written out as data."""
+import importlib.util
+import json
+import os
+from dataclasses import asdict, fields
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import PKG
+
+REFERENCE_FLAGS = [
+    "--config", "--vit-patch", "--vit-dim", "--vit-depth", "--vit-heads", "--out-dim", "--device", "--num-workers", "--pin-memory",
+    "--img-size", "--batch-size", "--accumulation-steps", "--lr", "--min-lr", "--warmup-steps", "--weight-decay", "--max-steps",
+    "--grad-checkpoint", "--ema", "--teacher-temp", "--student-temp", "--center-momentum", "--gram-weight", "--koleo-weight",
+    "--loss-type", "--scale-aware", "--ckpt-every", "--ckpt-keep-last", "--resume", "--monitor-every", "--index-csv",
+    "--split-manifest", "--crop-scale-min", "--crop-scale-max", "--z-stride", "--diverse-batches", "--train-seed", "--sdp-backend",
+    "--run-dir", "--run-suffix", "--amp", "--amp-dtype", "--log-json"]
+REFERENCE_DEFAULTS = {"config": "vit-large", "device": "auto", "img_size": 224, "batch_size": 64, "accumulation_steps": 1, "lr": 1e-4,
+                      "min_lr": 1e-6, "warmup_steps": 2500, "weight_decay": 0.04, "ema": 0.996, "teacher_temp": 0.04,
+                      "student_temp": 0.1, "center_momentum": 0.9, "gram_weight": 1.0, "koleo_weight": 0.0, "loss_type": "dino",
+                      "ckpt_every": 100, "ckpt_keep_last": 5, "monitor_every": 1000, "crop_scale_min": 0.3, "crop_scale_max": 1.0,
+                      "z_stride": 1, "train_seed": 0, "sdp_backend": "auto", "amp_dtype": "bfloat16", "max_steps": None, "resume": None}
+TRAINING_CONFIG_FIELDS = [
+    "model", "img_size", "hardware", "rw_level_min", "rw_level_max", "rw_width_min", "rw_width_max", "batch_size", "accumulation_steps",
+    "lr", "min_lr", "warmup_steps", "weight_decay", "max_steps", "ema", "teacher_temp", "student_temp", "center_momentum", "loss_type",
+    "gram_enabled", "gram_weight", "koleo_weight", "scale_aware", "crop_scale_min", "crop_scale_max", "z_stride", "diverse_batches",
+    "ckpt_every", "ckpt_keep_last", "monitor_every", "train_seed", "sdp_backend", "amp_dtype", "index_csv", "split_manifest",
+    "git_commit", "data_manifest_hash", "created_at"]
+
+
+@pytest.fixture(scope="module")
+def cli():
+    spec = importlib.util.spec_from_file_location("phase5_big_run", os.path.join(PKG, "scripts", "phase5_big_run.py"))
+    mod = importlib.util.module_from_spec(spec)
+    import sys
+    sys.modules[spec.name] = mod            # dataclasses resolve string annotations through sys.modules
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_flag_surface_matches_reference(cli):
+    ap = cli.build_parser()
+    have = {s for a in ap._actions for s in a.option_strings if s.startswith("--")} - {"--help"}
+    assert set(REFERENCE_FLAGS) <= have
+    assert have - set(REFERENCE_FLAGS) == {"--synthetic"}            # the one documented extension
+    d = vars(ap.parse_args([]))
+    for k, v in REFERENCE_DEFAULTS.items():
+        assert d[k] == v, k
+
+
+def test_importable_names(cli):
+    for n in ("DINOLoss", "DinoStudentTeacher", "PatchViT", "get_lr", "IndexRow", "PngDataset", "_load_index_rows", "dino_collate",
+              "ModelConfig", "MODEL_CONFIGS", "TrainingConfig", "HardwareConfig", "save_checkpoint", "load_checkpoint",
+              "find_latest_checkpoint", "rotate_checkpoints", "detect_anomaly", "DiverseBatchSampler", "compute_gram_anchoring_loss"):
+        assert hasattr(cli, n), n
+    assert cli.get_lr(0, None, 2500, 1e-4, 1e-6) == pytest.approx(4e-8)
+    assert cli.DINOLoss(64).center.shape == (1, 64) and cli.DINOLoss(64).center_momentum == 0.999
+
+
+def test_model_presets_and_overrides(cli):
+    p = cli.MODEL_CONFIGS
+    assert (p["vit-small"].patch, p["vit-small"].dim, p["vit-small"].depth, p["vit-small"].heads, p["vit-small"].out_dim) == (14, 384, 12, 6, 8192)
+    assert (p["vit-tiny"].dim, p["vit-tiny"].heads, p["vit-tiny"].out_dim) == (192, 3, 4096)
+    assert (p["vit-large"].dim, p["vit-large"].depth, p["vit-large"].heads) == (1024, 24, 16)
+    with pytest.raises(ValueError):
+        cli.ModelConfig("x", 16, 100, 2, 3)
+    ap = cli.build_parser()
+    cfg = cli.resolve_model_config(ap.parse_args(["--config", "vit-small", "--vit-patch", "16"]))
+    assert (cfg.name, cfg.patch, cfg.dim) == ("custom", 16, 384)                       # BASELINE's ViT-S/16
+    cfg = cli.resolve_model_config(ap.parse_args(["--config", "vit-small", "--vit-dim", "1024", "--vit-depth", "24", "--vit-heads", "16"]))
+    assert cfg.name == "vit-large"
+    with pytest.raises(ValueError):
+        cli.resolve_model_config(ap.parse_args(["--config", "custom", "--vit-patch", "16"]))
+    assert cli.resolve_model_config(ap.parse_args(["--config", "vit-small", "--out-dim", "1024"])).out_dim == 1024
+
+
+def test_training_config_fields_match_reference_payload(cli):
+    assert [f.name for f in fields(cli.TrainingConfig)] == TRAINING_CONFIG_FIELDS
+    cfg = cli.TrainingConfig(model=cli.MODEL_CONFIGS["vit-tiny"], batch_size=8, accumulation_steps=4)
+    assert cfg.effective_batch_size == 32 and cfg.gram_enabled is True
+    d = asdict(cfg)
+    assert d["model"]["name"] == "vit-tiny" and json.dumps(d)
+
+
+def _write_pngs(tmp_path, n_series=3, n_slices=4, size=64):
+    from PIL import Image
+    rows = []
+    for s in range(n_series):
+        for z in range(n_slices):
+            p = tmp_path / f"s{s}_z{z}.png"
+            arr = (32768 + 10 * np.random.default_rng(s * 10 + z).integers(-1000, 1000, size=(size, size))).astype(np.uint16)
+            Image.fromarray(arr).save(p)
+            rows.append(dict(png_path=str(p), series_dir=f"series{s}", slice_index=z, encoding="hu16_png", spacing_x=0.5 + 0.1 * s,
+                             spacing_y=0.5 + 0.1 * s, spacing_z=1.0 + s, dataset="toy"))
+    csv_path = tmp_path / "index.csv"
+    import csv as _csv
+    with open(csv_path, "w", newline="") as f:
+        w = _csv.DictWriter(f, fieldnames=list(rows[0]))
+        w.writeheader()
+        w.writerows(rows)
+    return csv_path
+
+
+def test_png_dataset_views_and_collate(cli, tmp_path):
+    rows = cli._load_index_rows(_write_pngs(tmp_path), require_spacing=True)
+    assert len(rows) == 12 and rows[5].spacing_z == 2.0 and rows[0].dataset == "toy"
+    ds = cli.PngDataset(rows, img_size=32, scale_aware=True)
+    (v1, v2), sp = ds[5]
+    assert v1.shape == v2.shape == (3, 32, 32) and v1.dtype == torch.float32 and sp.tolist() == pytest.approx([0.6, 0.6, 2.0])
+    assert not torch.equal(v1, v2)                                   # independent window + crop per view
+    lo, hi = (0 - 0.485) / 0.229 - 0.35, (1 - 0.406) / 0.225 + 0.35  # normalised [0,1] range (+ bicubic overshoot)
+    assert lo <= float(v1.min()) and float(v1.max()) <= hi
+    views, spb = cli.dino_collate([ds[i] for i in range(4)])
+    assert views[0].shape == views[1].shape == (4, 3, 32, 32) and spb.shape == (4, 3)
+    syn = cli.SyntheticSliceDataset(10, img_size=32, seed=3)
+    (a, b), s = syn[2]
+    (a2, _), _ = cli.SyntheticSliceDataset(10, img_size=32, seed=3)[2]
+    assert a.shape == (3, 32, 32) and 0.46 <= float(s[0]) <= 0.98 and 0.625 <= float(s[2]) <= 5.0
+
+
+def test_hu_window(cli):
+    u = np.array([[32768 + 400, 32768 - 10000, 65535]], dtype=np.uint16)       # 40 HU, -1000 HU, +3276.7 HU
+    w = cli.hu_window01(u, level=40.0, width=400.0)
+    np.testing.assert_allclose(w, [[0.5, 0.0, 1.0]], atol=1e-6)
+
+
+def test_diverse_batch_sampler(cli):
+    rows = [cli.IndexRow(png_path=f"{s}_{z}", series_dir=f"s{s}", slice_index=z, encoding="hu16_png") for s in range(6) for z in range(5)]
+    smp = cli.DiverseBatchSampler(rows, batch_size=4, drop_last=True, generator=torch.Generator().manual_seed(0))
+    batches = list(smp)
+    assert len(batches) == len(smp) == 7 and sorted(i for b in batches for i in b) != []
+    assert len({i for b in batches for i in b}) == 28                 # no repeats
+    for b in batches[:6]:                                             # while >= 4 series remain a batch never repeats a series
+        assert len({rows[i].series_dir for i in b}) == 4
+
+
+def test_detect_anomaly_and_rotation(cli, tmp_path):
+    assert cli.detect_anomaly(float("nan"), [])[0] and "NaN" in cli.detect_anomaly(float("nan"), [])[1]
+    assert cli.detect_anomaly(float("inf"), [])[1] == "Loss is Inf"
+    assert cli.detect_anomaly(5.0, [1.0] * 10)[0] and not cli.detect_anomaly(1.5, [1.0] * 10)[0]
+    assert cli.detect_anomaly(1.0, [], embedding_std=0.001)[0]
+    for i in (1, 2, 3, 4):
+        (tmp_path / f"checkpoint_{i:08d}.pth").write_bytes(b"x")
+    cli.rotate_checkpoints(tmp_path, 2)
+    assert sorted(p.name for p in tmp_path.glob("checkpoint_*.pth")) == ["checkpoint_00000003.pth", "checkpoint_00000004.pth"]
+    assert cli.find_latest_checkpoint(tmp_path).name == "checkpoint_00000004.pth"
+
+
+def test_checkpoint_payload_roundtrip_and_adamw_format(cli, tmp_path):
+    from dinox.engine import StepHyperParams, TrainEngine
+    import zoo.arch as arch
+    kw = dict(img_size=28, patch=14, dim=32, depth=1, heads=2, scale_aware=True)
+    torch.manual_seed(0)
+    student, teacher = arch.DinoStudentTeacher(arch.PatchViT(**kw), 48), arch.DinoStudentTeacher(arch.PatchViT(**kw), 48)
+    teacher.load_state_dict(student.state_dict())
+    eng = TrainEngine(student, teacher, 48, StepHyperParams())
+    eng.adam_m.normal_(); eng.adam_v.uniform_(0, 1); eng.center.normal_()
+    eng.opt_steps, eng.step_count = 7, 7
+    cfg = cli.TrainingConfig(model=cli.ModelConfig("custom", 14, 32, 1, 2, 4.0, 48), img_size=28, scale_aware=True)
+    path = tmp_path / "checkpoint_00000007.pth"
+    cli.save_checkpoint(path, 7, student, teacher, eng, cfg)
+    payload = torch.load(path, weights_only=False)
+    assert set(payload) == {"step", "student", "teacher", "opt", "scaler", "dino_loss", "rng", "config"}
+    assert payload["scaler"] is None and set(payload["rng"]) >= {"python", "numpy", "torch"} and payload["dino_loss"]["center"].shape == (1, 48)
+    assert list(payload["student"]) == list(student.state_dict()) and payload["config"]["model"]["dim"] == 32
+    # "opt" must be loadable by a stock torch.optim.AdamW over the same parameters (what the reference resumes with)
+    ref_opt = torch.optim.AdamW(student.parameters(), lr=1e-4, weight_decay=0.04)
+    ref_opt.load_state_dict(payload["opt"])
+    st = ref_opt.state[next(iter(student.parameters()))]
+    assert float(st["step"]) == 7.0 and st["exp_avg"].shape == next(iter(student.parameters())).shape
+    # and back into a fresh engine
+    s2, t2 = arch.DinoStudentTeacher(arch.PatchViT(**kw), 48), arch.DinoStudentTeacher(arch.PatchViT(**kw), 48)
+    eng2 = TrainEngine(s2, t2, 48, StepHyperParams())
+    step, loaded = cli.load_checkpoint(path, s2, t2, eng2, "cpu", scale_aware=True)
+    assert step == 7 and eng2.opt_steps == 7 and eng2.step_count == 7 and loaded.model.dim == 32 and loaded.scale_aware
+    assert torch.equal(eng2.flat_p, eng.flat_p) and torch.equal(eng2.adam_m, eng.adam_m) and torch.equal(eng2.adam_v, eng.adam_v)
+    assert torch.equal(eng2.center, eng.center)
+    with pytest.raises(FileNotFoundError):
+        cli.load_checkpoint(tmp_path / "missing.pth", s2, t2, eng2, "cpu")

@@ -23,7 +23,7 @@
 
 namespace dinox {
 
-constexpr int GG_BM = 128, GG_BN = 128, GG_THREADS = 256;
+constexpr int GG_BN = 128;
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_void;
@@ -40,12 +40,22 @@ enum { GG_PLAIN = 0, GG_GELU = 1, GG_DGELU = 2 };
 template <int CH>
 __device__ __forceinline__ int gg_swz(int row) { return CH == 8 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
 
-template <int OUT_DT, int ACT, bool RES, int GG_BK, int STAGES>
-__global__ __launch_bounds__(GG_THREADS, (GG_BK == 64 ? 2 : 3)) void gemm_bf16_nt_glds(GemmParams p, int tiles_m, int tiles_n) {
-  constexpr int GG_TILE = 128 * GG_BK * 2;        // bytes per operand tile per stage
+// 4 waves (2x2).  GG_BM = 128: each wave owns 64x64 (2x2 MFMA tiles);  GG_BM = 256: each wave owns 128x64 (4x2 tiles, 128
+// accumulator VGPRs).  The taller wave tile feeds 8 MFMAs from 6 fragment reads instead of 4 from 4 (LDS read traffic
+// per MFMA -25 %: with 64x64 wave tiles ds_read_b128 alone keeps the LDS ~50 % busy at the measured MFMA rate) and
+// re-uses every staged B tile for twice the rows (global->LDS bytes per FLOP -25 %).
+template <int OUT_DT, int ACT, bool RES, int GG_BK, int STAGES, int GG_BM>
+__global__ __launch_bounds__(256, (GG_BM == 256 ? 2 : (GG_BK == 64 ? 2 : 3))) void gemm_bf16_nt_glds(GemmParams p, int tiles_m, int tiles_n) {
+  constexpr int WAVES = 4;
+  constexpr int WM = GG_BM / 64;                  // 32-row MFMA tiles per wave along M (2 or 4)
+  constexpr int WROWS = 32 * WM;                  // rows per wave
+  constexpr int A_TILE = GG_BM * GG_BK * 2;       // bytes per stage
+  constexpr int B_TILE = GG_BN * GG_BK * 2;
+  constexpr int STAGE_BYTES = A_TILE + B_TILE;
   constexpr int CH = GG_BK / 8;                   // 16-B chunks per tile row
   constexpr int RPI = 64 / CH;                    // tile rows moved by one wave-instruction (1 KiB)
-  constexpr int NQ = 128 / RPI / 4;               // staging instructions per wave per operand
+  constexpr int NQA = GG_BM / RPI / WAVES;        // staging instructions per wave, A tile
+  constexpr int NQB = GG_BN / RPI / WAVES;        //                               B tile
   constexpr int ROWB = GG_BK * 2;                 // bytes per tile row
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -60,31 +70,36 @@ __global__ __launch_bounds__(GG_THREADS, (GG_BK == 64 ? 2 : 3)) void gemm_bf16_n
 
   // Per-lane source pointers of this wave's 4 + 4 staging instructions (each moves 8 rows x 128 B).
   // LDS slot (row, c') of a tile receives logical chunk c = c' ^ ((row>>1)&7) of that row.
-  const bf16_t* asrc[NQ];
-  const bf16_t* bsrc[NQ];
+  const bf16_t* asrc[NQA];
+  const bf16_t* bsrc[NQB];
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    const int row = (wv * NQ + q) * RPI + lane / CH;
+  for (int q = 0; q < NQA; ++q) {
+    const int row = (wv * NQA + q) * RPI + lane / CH;
     const int c = (lane % CH) ^ gg_swz<CH>(row);
-    int64_t gm = m0 + row, gn = n0 + row;
+    int64_t gm = m0 + row;
     gm = gm < p.M ? gm : p.M - 1;
-    gn = gn < p.N ? gn : p.N - 1;
     asrc[q] = A + gm * p.lda + c * 8;
+  }
+#pragma unroll
+  for (int q = 0; q < NQB; ++q) {
+    const int row = (wv * NQB + q) * RPI + lane / CH;
+    const int c = (lane % CH) ^ gg_swz<CH>(row);
+    int64_t gn = n0 + row;
+    gn = gn < p.N ? gn : p.N - 1;
     bsrc[q] = B + gn * p.ldb + c * 8;
   }
   auto stage = [&](int buf, int64_t k0) {
-    char* sa = smem + buf * 2 * GG_TILE + wv * (NQ * 1024);
-    char* sb = sa + GG_TILE;
+    char* sa = smem + buf * STAGE_BYTES + wv * (NQA * 1024);
+    char* sb = smem + buf * STAGE_BYTES + A_TILE + wv * (NQB * 1024);
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      __builtin_amdgcn_global_load_lds((gbl_void*)(asrc[q] + k0), (lds_void*)(sa + q * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gbl_void*)(bsrc[q] + k0), (lds_void*)(sb + q * 1024), 16, 0, 0);
-    }
+    for (int q = 0; q < NQA; ++q) __builtin_amdgcn_global_load_lds((gbl_void*)(asrc[q] + k0), (lds_void*)(sa + q * 1024), 16, 0, 0);
+#pragma unroll
+    for (int q = 0; q < NQB; ++q) __builtin_amdgcn_global_load_lds((gbl_void*)(bsrc[q] + k0), (lds_void*)(sb + q * 1024), 16, 0, 0);
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[WM][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < WM; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -93,20 +108,24 @@ __global__ __launch_bounds__(GG_THREADS, (GG_BK == 64 ? 2 : 3)) void gemm_bf16_n
   const int nk = (int)(p.K / GG_BK);
   const int frow = lane & 31, fh = lane >> 5;
   auto compute = [&](int buf) {
-    const char* sa = smem + buf * 2 * GG_TILE;
-    const char* sb = sa + GG_TILE;
+    const char* sa = smem + buf * STAGE_BYTES;
+    const char* sb = sa + A_TILE;
 #pragma unroll
     for (int ks = 0; ks < GG_BK / 16; ++ks) {
-      bf16x8 af[2], bfr[2];
+      bf16x8 af[WM], bfr[2];
+      const int kc = 2 * ks + fh;
+#pragma unroll
+      for (int i = 0; i < WM; ++i) {
+        const int ra = wr * WROWS + i * 32 + frow;
+        af[i] = *reinterpret_cast<const bf16x8*>(sa + ra * ROWB + ((kc ^ gg_swz<CH>(ra)) << 4));
+      }
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const int ra = wr * 64 + i * 32 + frow, rb = wc * 64 + i * 32 + frow;
-        const int kc = 2 * ks + fh;
-        af[i] = *reinterpret_cast<const bf16x8*>(sa + ra * ROWB + ((kc ^ gg_swz<CH>(ra)) << 4));
+        const int rb = wc * 64 + i * 32 + frow;
         bfr[i] = *reinterpret_cast<const bf16x8*>(sb + rb * ROWB + ((kc ^ gg_swz<CH>(rb)) << 4));
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < WM; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
@@ -129,7 +148,7 @@ __global__ __launch_bounds__(GG_THREADS, (GG_BK == 64 ? 2 : 3)) void gemm_bf16_n
     if (nk > 1) stage(1, GG_BK);
     int buf = 0;
     for (int kt = 0; kt < nk; ++kt) {
-      if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NQ) : "memory");
+      if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQA + NQB) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
@@ -143,8 +162,8 @@ __global__ __launch_bounds__(GG_THREADS, (GG_BK == 64 ? 2 : 3)) void gemm_bf16_n
   // ---- epilogue: park the wave's accumulator block in LDS (row = 256 B, 16-B chunks XOR (row&15)) and re-read it by
   // rows.  With BK = 64 the four waves park 64 rows each at once (64 KiB = both stages); with BK = 32 the stages are
   // 32 KiB, so each wave parks its two 32-row halves one after the other.
-  constexpr int PASSES = (STAGES * 2 * GG_TILE >= 65536) ? 1 : 2;
-  constexpr int PROWS = 64 / PASSES;
+  constexpr int PASSES = (STAGES * STAGE_BYTES >= WAVES * WROWS * 256) ? 1 : WM;    // one pass, or one 32-row MFMA tile row per pass
+  constexpr int PROWS = WROWS / PASSES;
   char* park = smem + wv * (PROWS * 256);
   const int c8 = lane & 7;
   const int64_t n = n0 + wc * 64 + c8 * 8;
@@ -161,13 +180,13 @@ __global__ __launch_bounds__(GG_THREADS, (GG_BK == 64 ? 2 : 3)) void gemm_bf16_n
 #pragma unroll
   for (int ps = 0; ps < PASSES; ++ps) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      if (PASSES == 2 && i != ps) continue;
+    for (int i = 0; i < WM; ++i) {
+      if (PASSES != 1 && i != ps) continue;
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const int row = (PASSES == 2 ? 0 : i * 32) + (e & 3) + 8 * (e >> 2) + 4 * fh;
+          const int row = (PASSES != 1 ? 0 : i * 32) + (e & 3) + 8 * (e >> 2) + 4 * fh;
           const int nn = j * 32 + frow;
           *reinterpret_cast<float*>(park + row * 256 + ((((nn >> 2) ^ (row & 15))) << 4) + (nn & 3) * 4) = acc[i][j][e];
         }
@@ -177,7 +196,7 @@ __global__ __launch_bounds__(GG_THREADS, (GG_BK == 64 ? 2 : 3)) void gemm_bf16_n
 #pragma unroll
     for (int it = 0; it < PROWS / 8; ++it) {
       const int row = it * 8 + (lane >> 3);
-      const int64_t m = m0 + wr * 64 + ps * PROWS + row;
+      const int64_t m = m0 + wr * WROWS + ps * PROWS + row;
       const float4 lo = *reinterpret_cast<const float4*>(park + row * 256 + (((2 * c8) ^ (row & 15)) << 4));
       const float4 hi = *reinterpret_cast<const float4*>(park + row * 256 + (((2 * c8 + 1) ^ (row & 15)) << 4));
       if (m >= p.M || !n_ok) continue;
@@ -251,7 +270,7 @@ __global__ __launch_bounds__(GG_THREADS, (GG_BK == 64 ? 2 : 3)) void gemm_bf16_n
         *reinterpret_cast<float4*>((float*)p.C + ci + 4) = make_float4(v[4], v[5], v[6], v[7]);
       }
     }
-    if (PASSES == 2) {
+    if (PASSES != 1) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
@@ -275,21 +294,38 @@ bool gemm_bf16_nt_glds_ok(const GemmParams& p) {
 }
 
 int launch_gemm_bf16_nt_glds(const GemmParams& p, hipStream_t st) {
-  const int tiles_m = (int)ceil_div(p.M, GG_BM), tiles_n = (int)ceil_div(p.N, GG_BN);
+  static const int knob = getenv("DINOX_NT_BK") ? atoi(getenv("DINOX_NT_BK")) : 0;   // tuning knobs (A/B testing)
+  static const int knob_bm = getenv("DINOX_NT_BM") ? atoi(getenv("DINOX_NT_BM")) : 0;
+  // measured (tools/gemm_bench.py): K <= 512 runs faster on the 3-stage BK=32 ring, longer K on the 2-stage BK=64 form
+  const int bk = knob ? knob : (p.K <= 512 ? 32 : 64);
+  // the 256-row tile (128x64 per wave) measures within +-5 % of the 128-row tile on every hot-path shape (tools/gemm_bench.py),
+  // so the smaller one (more workgroups per CU, finer tail) stays the default; DINOX_NT_BM=256 selects the other
+  const int bm = knob_bm ? knob_bm : 128;
+  const int stages = bk == 64 ? 2 : 3;
+
+  const int tiles_m = (int)ceil_div(p.M, bm), tiles_n = (int)ceil_div(p.N, GG_BN);
   const int64_t ntile = (int64_t)tiles_m * tiles_n;
   if (ntile > 0x7fffffff) return DINOX_EUNSUPPORTED;
   dim3 grid((unsigned)ntile, (unsigned)p.batch);
-  static const int knob = getenv("DINOX_NT_BK") ? atoi(getenv("DINOX_NT_BK")) : 0;   // tuning knob: 64 | 32 (3-stage)
-  // measured (tools/gemm_bench.py): K <= 512 runs 6-12 % faster on the 3-stage BK=32 ring (3 workgroups/CU), longer K on
-  // the 2-stage BK=64 form
-  const int bk = knob ? knob : (p.K <= 512 ? 32 : 64);
-  const size_t lds = (bk == 64 ? 4 : 6) * (size_t)128 * bk * 2;
+  const size_t lds = (size_t)stages * (bm + GG_BN) * bk * 2;
   const int act = (p.epilogue & DINOX_EPI_GELU) ? GG_GELU : (p.epilogue & DINOX_EPI_DGELU) ? GG_DGELU : GG_PLAIN;
   const bool res = (p.epilogue & DINOX_EPI_RESIDUAL) != 0;
-#define GG(OUT, ACT, RES)                                                                                              \
-  do {                                                                                                                  \
-    if (bk == 32) hipLaunchKernelGGL((gemm_bf16_nt_glds<OUT, ACT, RES, 32, 3>), grid, dim3(GG_THREADS), lds, st, p, tiles_m, tiles_n); \
-    else hipLaunchKernelGGL((gemm_bf16_nt_glds<OUT, ACT, RES, 64, 2>), grid, dim3(GG_THREADS), lds, st, p, tiles_m, tiles_n);          \
+#define GG_L(OUT, ACT, RES, BK, ST, BM)                                                                                  \
+  do {                                                                                                                    \
+    auto kern = gemm_bf16_nt_glds<OUT, ACT, RES, BK, ST, BM>;                                                             \
+    if (lds > 64 * 1024) {                                                                                                \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      if (e != hipSuccess) return fail((int)e, "gemm_bf16_nt_glds: cannot reserve %zu B of LDS", lds);                    \
+    }                                                                                                                     \
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p, tiles_m, tiles_n);                                           \
+  } while (0)
+#define GG(OUT, ACT, RES)                                                       \
+  do {                                                                          \
+    if (bm == 256) {                                                            \
+      if (bk == 32) GG_L(OUT, ACT, RES, 32, 3, 256); else GG_L(OUT, ACT, RES, 64, 2, 256); \
+    } else {                                                                    \
+      if (bk == 32) GG_L(OUT, ACT, RES, 32, 3, 128); else GG_L(OUT, ACT, RES, 64, 2, 128); \
+    }                                                                           \
   } while (0)
 #define GG_ACT(OUT, RES)                                                                  \
   do {                                                                                    \
@@ -302,6 +338,7 @@ int launch_gemm_bf16_nt_glds(const GemmParams& p, hipStream_t st) {
   }
 #undef GG_ACT
 #undef GG
+#undef GG_L
   return check_launch("gemm_bf16_nt_glds");
 }
 

@@ -99,6 +99,7 @@ def main() -> None:
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    local = local % torch.cuda.device_count()        # (rehearsals may put several gloo ranks on one GPU)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 

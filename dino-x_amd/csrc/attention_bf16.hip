@@ -93,6 +93,10 @@ __device__ __forceinline__ void store_tile(bf16_t* __restrict__ dst, int64_t row
 }
 
 // ------------------------------------------------------------------------------------------ forward
+// Two passes over the key tiles: pass 1 keeps only the running row maximum, pass 2 recomputes each S^T tile, exponentiates
+// against the exact maximum and feeds P straight into the PV MFMAs.  Holding all NKT score tiles instead (one pass) costs
+// 16*NKT accumulator VGPRs (188 total at N=201): one 7-wave workgroup per CU, load phase and MFMA phase never overlap.
+// This form needs ~100 VGPRs -> two workgroups per CU overlap each other's K/V staging; the extra QK^T MFMAs are cheap.
 template <int NKT>
 __global__ __launch_bounds__(512) void attn_fwd_bf16(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
                                                      float* __restrict__ lse, int N, int heads, float sc) {
@@ -105,6 +109,7 @@ __global__ __launch_bounds__(512) void attn_fwd_bf16(const bf16_t* __restrict__ 
   const int npad = NKT * 32;
   char* kimg = smem;
   char* vimg = smem + npad * 128;
+  float* inv_s = reinterpret_cast<float*>(smem + 2 * npad * 128) + wv * 32;   // per-wave 1/rowsum, query-indexed
   load_image(kimg, base + C, rs, N, npad);
   load_image(vimg, base + 2 * C, rs, N, npad);
   __syncthreads();
@@ -116,49 +121,64 @@ __global__ __launch_bounds__(512) void attn_fwd_bf16(const bf16_t* __restrict__ 
   bf16x8 qf[4];
   load_row_frags(qf, base + (int64_t)qrow * rs, lane);
 
-  f32x16 s[NKT];
   float mx = -INFINITY;
-#pragma unroll
+#pragma unroll 1
   for (int kt = 0; kt < NKT; ++kt) {
-    zero16(s[kt]);
+    f32x16 s;
+    zero16(s);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
-      s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(kimg, kt * 32, ks, lane), qf[ks], s[kt], 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(kimg, kt * 32, ks, lane), qf[ks], s, 0, 0, 0);
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int key = kt * 32 + acc_row(e, hl);
-      const float v = key < N ? s[kt][e] * sc : -INFINITY;
-      s[kt][e] = v;
-      mx = fmaxf(mx, v);
+      mx = fmaxf(mx, key < N ? s[e] : -INFINITY);
     }
   }
-  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-  float sum = 0.f;
-#pragma unroll
-  for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const float p = __expf(s[kt][e] - mx);
-      s[kt][e] = p;
-      sum += p;
-    }
-  sum += __shfl_xor(sum, 32, 64);
-  const float inv = 1.0f / sum;
-  if (hl == 0 && q0 + lane < N) lse[((int64_t)b * heads + hh) * N + q0 + lane] = mx + __logf(sum);
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * sc;                      // sc > 0: max commutes with the scaling
 
   f32x16 oacc[2];
   zero16(oacc[0]);
   zero16(oacc[1]);
-#pragma unroll
+  float sum = 0.f;
+#pragma unroll 1
   for (int kt = 0; kt < NKT; ++kt) {
+    f32x16 s;
+    zero16(s);
 #pragma unroll
-    for (int e = 0; e < 16; ++e) s[kt][e] *= inv;                  // normalise while the query is still lane-local
+    for (int ks = 0; ks < 4; ++ks)
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(kimg, kt * 32, ks, lane), qf[ks], s, 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int key = kt * 32 + acc_row(e, hl);
+      const float p = key < N ? __expf(s[e] * sc - mx) : 0.f;
+      s[e] = p;
+      sum += p;
+    }
 #pragma unroll
     for (int ss = 0; ss < 2; ++ss) {
-      const bf16x8 pa = acc_as_a(s[kt], ss);
+      const bf16x8 pa = acc_as_a(s, ss);
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
         oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, frag_tr_perm(vimg, kt * 32, ss, dt * 32, lane), oacc[dt], 0, 0, 0);
+    }
+  }
+  sum += __shfl_xor(sum, 32, 64);
+  if (hl == 0) {
+    inv_s[lane] = 1.0f / sum;                                       // lane = query within the block
+    if (q0 + lane < N) lse[((int64_t)b * heads + hh) * N + q0 + lane] = mx + __logf(sum);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  // O rows are queries in the accumulator layout: fetch each row's 1/sum (4 consecutive rows per register group)
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float4 iv = *reinterpret_cast<const float4*>(inv_s + 8 * g + 4 * hl);
+    const float ivv[4] = {iv.x, iv.y, iv.z, iv.w};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      oacc[0][4 * g + r] *= ivv[r];
+      oacc[1][4 * g + r] *= ivv[r];
     }
   }
   bf16_t* ob = o + (int64_t)b * N * C + hh * AT_D;
@@ -339,7 +359,7 @@ int launch_attention_bf16_fwd(const void* qkv, void* o, float* lse, int B, int N
   dim3 grid((unsigned)(B * heads), (unsigned)nwg), block((unsigned)(waves * 64));
 #define FWD(NKT)                                                                                                   \
   do {                                                                                                             \
-    const size_t lds = (size_t)2 * NKT * 32 * 128;                                                                 \
+    const size_t lds = (size_t)2 * NKT * 32 * 128 + 8 * 32 * sizeof(float);                                        \
     if (int rc = allow_lds(attn_fwd_bf16<NKT>, lds)) return fail(rc, "attention_fwd: cannot reserve %zu B of LDS", lds); \
     hipLaunchKernelGGL((attn_fwd_bf16<NKT>), grid, block, lds, st, (const bf16_t*)qkv, (bf16_t*)o, lse, N, heads, sc); \
   } while (0)

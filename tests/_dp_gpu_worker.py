@@ -1,0 +1,43 @@
+"""Worker of test_engine_data_parallel_two_ranks_match_single_process: one TrainEngine step (fp32 parity mode) on this
+rank's shard of a fixed global batch.  Run with RANK/WORLD_SIZE/MASTER_* set (WORLD_SIZE=1: whole batch)."""
+import os
+import sys
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path[:0] = [ROOT, os.path.join(ROOT, "dino-x_amd")]
+
+from dinox.dp import init_process_group, shard_range  # noqa: E402
+from dinox.engine import StepHyperParams, TrainEngine  # noqa: E402
+import zoo.arch as arch  # noqa: E402
+
+rank, world, local = init_process_group()
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+kw = dict(img_size=56, patch=14, dim=64, depth=2, heads=2, num_registers=4, scale_aware=True)
+torch.manual_seed(100 + rank)                      # different init per rank: the engine must broadcast rank 0's weights
+if world == 1:
+    torch.manual_seed(100)
+student = arch.DinoStudentTeacher(arch.PatchViT(**kw), 256)
+torch.nn.init.xavier_uniform_(student.backbone.scale_embed.mlp[2].weight)
+teacher = arch.DinoStudentTeacher(arch.PatchViT(**kw), 256)
+teacher.load_state_dict(student.state_dict())
+eng = TrainEngine(student.to(dev), teacher.to(dev), 256, StepHyperParams(lr=1e-3, warmup_steps=1, max_steps=10, ema=0.99),
+                  bucket_bytes=64 << 10)
+assert world == 1 or len(eng.bucketer.buckets) >= 3
+g = torch.Generator().manual_seed(7)
+B = 8
+v1, v2 = torch.randn(B, 3, 56, 56, generator=g), torch.randn(B, 3, 56, 56, generator=g)
+sp = torch.rand(B, 3, generator=g) * 2 + 0.4
+lo, hi = shard_range(B, rank, world)
+batch = torch.cat([v1[lo:hi], v2[lo:hi]], 0).to(dev)
+sp2 = torch.cat([sp[lo:hi], sp[lo:hi]], 0).to(dev)
+for _ in range(2):
+    eng.step(batch, sp2)
+sc = eng.scalars()
+torch.save({"flat_p": eng.flat_p.cpu(), "center": eng.center.cpu(), "loss": sc["loss"], "grad_norm": sc["grad_norm"]}, sys.argv[1])
+if world > 1:
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()

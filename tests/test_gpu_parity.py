@@ -547,3 +547,32 @@ def test_cli_train_checkpoint_resume(dx, tmp_path, capsys):
     assert f.shape == (1, 1, 64) and torch.isfinite(f).all()
     fb = enc.encode_batch(bb, [np.zeros((40, 40), np.float32), np.ones((3, 40, 40), np.float32)], [(0.5, 0.5, 1.0), (1.0, 1.0, 3.0)])
     assert fb.shape == (2, 1, 64)
+
+
+# ------------------------------------------------------------------------------------------ data parallel on a real device
+def test_engine_data_parallel_two_ranks_match_single_process(dx, tmp_path):
+    """Two ranks (gloo, both on this GPU -- RCCL needs one GPU per rank) run TrainEngine.step on their shard of a
+    global batch; the result must equal the single-process step at the global batch: same loss, same
+    updated weights, same centre.  Exercises broadcast, bucket hooks, centre all-reduce and the 1/world AdamW scale."""
+    import os, socket, subprocess, sys
+    from conftest import ROOT
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    worker = os.path.join(ROOT, "tests", "_dp_gpu_worker.py")
+    outs = [str(tmp_path / f"r{r}.pt") for r in range(2)]
+    env = dict(os.environ, DINOX_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, worker, outs[r]], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    logs = [p.communicate(timeout=240)[0].decode(errors="replace")[-1500:] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    single = subprocess.run([sys.executable, worker, str(tmp_path / "single.pt")], env=dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"),
+                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
+    assert single.returncode == 0, single.stdout.decode(errors="replace")[-1500:]
+    a, b, ref = torch.load(outs[0]), torch.load(outs[1]), torch.load(tmp_path / "single.pt")
+    assert torch.equal(a["flat_p"], b["flat_p"]) and torch.equal(a["center"], b["center"])        # ranks stay in lock-step
+    mean_loss = 0.5 * (a["loss"] + b["loss"])
+    assert mean_loss == pytest.approx(ref["loss"], rel=2e-4)
+    assert a["grad_norm"] == pytest.approx(ref["grad_norm"], rel=2e-3)
+    close(a["center"], ref["center"], 1e-4, 1e-7, "centre")
+    d = (a["flat_p"] - ref["flat_p"]).abs()
+    assert float((d <= 1e-5 + 1e-4 * ref["flat_p"].abs()).double().mean()) > 0.995     # Adam sign-noise on ~zero grads aside
+    assert float(d.max()) <= 2.5e-3

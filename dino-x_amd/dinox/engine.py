@@ -22,6 +22,7 @@ weight decay to them.  The reference loop always passes spacing for scale-aware 
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import List, Optional, Tuple
 
@@ -97,6 +98,9 @@ class TrainEngine:
         dev = self.flat_p.device
         self.center = torch.zeros(1, out_dim, dtype=torch.float32, device=dev)
         self.bucketer = GradBucketer(self.params, self.offsets, self.flat_g, bucket_bytes=bucket_bytes, group=process_group)
+        # the teacher forward has no data dependence on the student forward: it runs on its own HIP stream so the two
+        # kernel chains fill each other's tails (every launch ends with a partial last round of workgroups)
+        self.side_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self.step_count = 0          # micro-batches seen (drives the LR schedule, like the reference)
         self.opt_steps = 0           # optimiser steps taken (AdamW bias correction)
         self.last = {}
@@ -110,10 +114,23 @@ class TrainEngine:
         self.flat_g.zero_()
         self.bucketer.arm()
         with ops.compute_dtype(self.compute_dtype):
-            s_feats = self.student.backbone(batch, spacing=spacing2b)
-            with torch.no_grad():
-                t_feats = self.teacher.backbone(batch, spacing=spacing2b)
-                t_out = self.teacher.head(t_feats[:, 0])
+            main = torch.cuda.current_stream()
+            side = self.side_stream if os.environ.get("DINOX_NO_SIDE_STREAM") is None else None
+            if side is not None:
+                ops.patch_unfold(batch, self.student.backbone.patch, self.compute_dtype)     # shared by both nets: before the fork
+                side.wait_stream(main)
+                with torch.cuda.stream(side), torch.no_grad():
+                    t_feats = self.teacher.backbone(batch, spacing=spacing2b)
+                    t_out = self.teacher.head(t_feats[:, 0])
+                s_feats = self.student.backbone(batch, spacing=spacing2b)
+                main.wait_stream(side)
+                t_feats.record_stream(main)
+                t_out.record_stream(main)
+            else:
+                s_feats = self.student.backbone(batch, spacing=spacing2b)
+                with torch.no_grad():
+                    t_feats = self.teacher.backbone(batch, spacing=spacing2b)
+                    t_out = self.teacher.head(t_feats[:, 0])
             s_out = self.student.head(s_feats[:, 0])
             l_dino = ops.DinoCEFn.apply(s_out, t_out, self.center, hp.student_temp, hp.teacher_temp)
             # centre EMA after the loss used the old centre; batch mean is global under DP

@@ -40,6 +40,12 @@ dbd = torch.empty(D, device=dev)
 case("dW2   TN M384 N1536  (+db)       ", lambda: ops.gemm(x, xh, transA=True, transB=True, out_dtype=torch.float32, colsum_out=dbd), 2 * M * D * H, M * H * 2 + M * D * 2)
 case("dWp   TN M384 N384   (+db)       ", lambda: ops.gemm(x, x, transA=True, transB=True, out_dtype=torch.float32, colsum_out=dbd), 2 * M * D * D, 2 * M * D * 2)
 
+if os.environ.get("SQUARE"):
+    S = int(os.environ["SQUARE"])
+    sa, sb = rb(S, S), rb(S, S)
+    case(f"square NT {S}^3 plain          ", lambda: ops.gemm(sa, sb), 2 * S ** 3, 3 * S * S * 2)
+    case(f"square TN {S}^3 plain f32out   ", lambda: ops.gemm(sa, sb, transA=True, transB=True, out_dtype=torch.float32), 2 * S ** 3, 2 * S * S * 2 + S * S * 4)
+
 sel = os.environ.get("CASES")
 names = [n for n in cases if not sel or any(s in n for s in sel.split(","))]
 for n in names:

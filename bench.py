@@ -172,6 +172,17 @@ def main() -> None:
                         kernel_share_of_step=round(d["ms"] / (dt * 1e3), 4),
                         all_gemm_kernels={k: {"launches": v["launches"], "ms": round(v["ms"], 3),
                                               "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in kernels.items()})
+        # HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE and, in a
+        # separate run, WRITE_SIZE of this same command; FETCH doubled per the gfx950 correction) -- bench.py cannot
+        # run the profiler on itself, so the figure is read from profiles/ and is null when that file is absent.
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            fam = "dinox::" + roof.get("kernel", "")
+            if fam in pmc:
+                roof["traffic"] = pmc[fam]["hbm_bytes_per_launch"]
+                roof["traffic_note"] = "avg HBM bytes/launch, profiles/r01_pmc_traffic.json; algorithmic avg ~447e6 (operands+outputs once)"
+        except (OSError, ValueError, KeyError):
+            pass
         roof["step"] = {"gflop_per_sample": round(gf_sample, 2), "achieved": round(step_tflops, 2),
                         "frac": round(step_tflops / PEAK_BF16_DENSE_TFLOPS, 4)}
         line = {

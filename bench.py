@@ -84,6 +84,8 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch-size", type=int, default=256, help="source samples per GPU")
     ap.add_argument("--fp32", action="store_true", help="parity mode (exact-fp32 MFMA) instead of bf16")
+    ap.add_argument("--model", choices=["vit-small", "vit-large"], default="vit-small",
+                    help="vit-small = BASELINE configs[2] (the metric's config); vit-large = configs[4] shape (not the headline metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket GEMM launches with HIP events")
     args = ap.parse_args()
@@ -104,6 +106,8 @@ def main() -> None:
     dev = torch.device("cuda", local)
 
     cfg_kw = dict(img_size=224, patch=16, dim=384, depth=12, heads=6, num_registers=4, scale_aware=True)
+    if args.model == "vit-large":
+        cfg_kw.update(dim=1024, depth=24, heads=16)
     out_dim, B = 8192, args.batch_size
     torch.manual_seed(0)
     student = arch.DinoStudentTeacher(arch.PatchViT(**cfg_kw), out_dim)
@@ -160,7 +164,7 @@ def main() -> None:
     kernels = timer.summary() if timer else {}
     if rank == 0:
         samples_s = world * B * args.steps / dt
-        gf_sample = 8.0 * fwd_flops_per_image() / 1e9
+        gf_sample = 8.0 * fwd_flops_per_image(dim=cfg_kw["dim"], depth=cfg_kw["depth"]) / 1e9
         step_tflops = samples_s * gf_sample / 1e3 / world          # per GPU
         roof = {"bound": "mfma", "achieved": None, "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None}
         if kernels:
@@ -178,7 +182,7 @@ def main() -> None:
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
             fam = "dinox::" + roof.get("kernel", "")
-            if fam in pmc:
+            if fam in pmc and args.model == "vit-small" and B == 256:
                 roof["traffic"] = pmc[fam]["hbm_bytes_per_launch"]
                 roof["traffic_note"] = "avg HBM bytes/launch, profiles/r01_pmc_traffic.json; algorithmic avg ~447e6 (operands+outputs once)"
         except (OSError, ValueError, KeyError):
@@ -186,11 +190,12 @@ def main() -> None:
         roof["step"] = {"gflop_per_sample": round(gf_sample, 2), "achieved": round(step_tflops, 2),
                         "frac": round(step_tflops / PEAK_BF16_DENSE_TFLOPS, 4)}
         line = {
-            "metric": "training images/sec (source samples; 2 global views each) ViT-S/16 224px bs256/GPU",
+            "metric": "training images/sec (source samples; 2 global views each) ViT-S/16 224px bs256/GPU" if args.model == "vit-small"
+            else "training images/sec (source samples; 2 global views each) ViT-L/16 224px (configs[4] shape, not the headline metric)",
             "value": round(samples_s, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.fp32 else "bf16", "data": "synthetic",
-            "config": {"workload": "ViT-S/16 224x224x3 2.5D slice stacks, scale-aware, 2 views/sample, DINO+Gram loss, AdamW+EMA",
+            "config": {"workload": ("ViT-S" if args.model == "vit-small" else "ViT-L") + "/16 224x224x3 2.5D slice stacks, scale-aware, 2 views/sample, DINO+Gram loss, AdamW+EMA",
                        "per_gpu_batch": B, "global_batch": B * world, "views_per_step": 2 * B * world, "tokens": 201, "out_dim": out_dim,
                        "parallelism": f"dp{world}", "views_per_s": round(2 * samples_s, 2),
                        "loss": round(scal["loss"], 5), "grad_norm": round(scal["grad_norm"], 5)},
@@ -198,7 +203,7 @@ def main() -> None:
         }
         if world == 1 and not args.no_cpu_baseline:
             note("timing the CPU oracle (cpu_baseline) ...")
-            line["cpu_baseline"] = cpu_baseline(cfg_kw, out_dim)
+            line["cpu_baseline"] = cpu_baseline(cfg_kw, out_dim) if args.model == "vit-small" else None
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

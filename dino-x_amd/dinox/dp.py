@@ -93,6 +93,7 @@ class GradBucketer:
                 for j in members:
                     self.bucket_of[j] = b
                 hi = None
+        self.active = True          # False on all but the last micro-batch of a gradient-accumulation group
         self._hooks = []
         if self.world > 1:
             for i, p in enumerate(params):
@@ -112,12 +113,12 @@ class GradBucketer:
     def grad_ready(self, i: int) -> None:
         b = self.buckets[self.bucket_of[i]]
         b.pending -= 1
-        if b.pending == 0 and self.world > 1:
+        if b.pending == 0 and self.world > 1 and self.active:
             b.work = dist.all_reduce(self.flat[b.lo:b.hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def finish(self) -> None:
         """Launch any bucket that never filled (parameters without gradient) and wait for all."""
-        if self.world <= 1:
+        if self.world <= 1 or not self.active:
             return
         for b in self.buckets:
             if b.work is None:

@@ -76,8 +76,12 @@ class TrainEngine:
     """Owns student/teacher arenas, the DINO centre and the optimiser state; ``step()`` runs one update."""
 
     def __init__(self, student: torch.nn.Module, teacher: torch.nn.Module, out_dim: int, hp: StepHyperParams,
-                 amp_dtype: Optional[torch.dtype] = None, process_group=None, bucket_bytes: int = 32 << 20) -> None:
+                 amp_dtype: Optional[torch.dtype] = None, process_group=None, bucket_bytes: int = 32 << 20,
+                 accumulation_steps: int = 1) -> None:
         self.student, self.teacher, self.hp = student, teacher, hp
+        if accumulation_steps < 1:
+            raise ValueError("accumulation_steps must be >= 1")
+        self.accum = accumulation_steps
         self.compute_dtype = amp_dtype or torch.float32
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -111,7 +115,14 @@ class TrainEngine:
         Returns device tensors {loss, dino, gram, grad_norm_sq} and the python float lr (no sync)."""
         hp = self.hp
         lr = get_lr(self.step_count, hp.max_steps, hp.warmup_steps, hp.lr, hp.min_lr)
-        self.flat_g.zero_()
+        # gradient accumulation with the reference's semantics (phase5_big_run.py:1769-1796): `step` counts micro-batches,
+        # loss/accum is back-propagated every micro-batch, the optimiser (and EMA) run when (step+1) % accum == 0 with the LR
+        # of that micro-batch, the centre moves every micro-batch.  Gradients are exchanged once, on the last micro-batch.
+        first = self.step_count % self.accum == 0
+        last = (self.step_count + 1) % self.accum == 0
+        if first:
+            self.flat_g.zero_()
+        self.bucketer.active = last
         self.bucketer.arm()
         with ops.compute_dtype(self.compute_dtype):
             main = torch.cuda.current_stream()
@@ -143,13 +154,16 @@ class TrainEngine:
             else:
                 l_gram = torch.zeros((), device=batch.device)
                 loss = l_dino
-            loss.backward()
+            (loss if self.accum == 1 else loss / self.accum).backward()
         self.bucketer.finish()
-        self.opt_steps += 1
-        gsq = ops.adamw_ema_(self.flat_p, self.flat_g, self.adam_m, self.adam_v, self.flat_t, lr=lr,
-                             weight_decay=hp.weight_decay, beta1=hp.beta1, beta2=hp.beta2, eps=hp.adam_eps,
-                             step_t=self.opt_steps, ema=hp.ema, grad_scale=1.0 / self.world)
-        ops.weight_cache.clear()     # master weights changed under the bf16 copies
+        if last:
+            self.opt_steps += 1
+            gsq = ops.adamw_ema_(self.flat_p, self.flat_g, self.adam_m, self.adam_v, self.flat_t, lr=lr,
+                                 weight_decay=hp.weight_decay, beta1=hp.beta1, beta2=hp.beta2, eps=hp.adam_eps,
+                                 step_t=self.opt_steps, ema=hp.ema, grad_scale=1.0 / self.world)
+            ops.weight_cache.clear()     # master weights changed under the bf16 copies
+        else:
+            gsq = torch.zeros(1, device=batch.device)       # the reference logs grad-norm 0 between optimiser steps
         self.step_count += 1
         self.last = {"loss": loss.detach(), "dino": l_dino.detach(), "gram": l_gram.detach(), "grad_norm_sq": gsq, "lr": lr}
         return self.last

@@ -16,7 +16,7 @@ loop :1686-1997), and the same importable names other reference scripts/tests us
 * the input pipeline is torchvision-free (PIL + torch CPU ops) and there is an explicit ``--synthetic N`` source of
   seeded 16-bit HU slice stacks for runs without a dataset (this environment has none);
 * not wired to the engine yet (exit with a message): ``--loss-type simclr|mae``, ``--koleo-weight > 0``,
-  ``--accumulation-steps > 1``, ``--device cpu`` (there is no CPU compute path).
+  ``--device cpu`` (there is no CPU compute path).
 """
 from __future__ import annotations
 
@@ -576,8 +576,6 @@ def main(argv=None) -> None:
         raise SystemExit(f"--loss-type {args.loss_type} is not wired to the MI355X engine yet (only 'dino'; see DESIGN.md section 7)")
     if args.koleo_weight > 0.0:
         raise SystemExit("--koleo-weight > 0 is not wired to the MI355X engine yet (see DESIGN.md section 7)")
-    if args.accumulation_steps != 1:
-        raise SystemExit("--accumulation-steps > 1 is not wired to the MI355X engine yet (see DESIGN.md section 7)")
     if args.amp and args.amp_dtype != "bfloat16":
         raise SystemExit("the HIP path supports --amp-dtype bfloat16 only")
     rank, world, local = init_process_group()
@@ -699,7 +697,8 @@ def main(argv=None) -> None:
     hp = StepHyperParams(lr=args.lr, min_lr=args.min_lr, warmup_steps=args.warmup_steps, max_steps=args.max_steps,
                          weight_decay=args.weight_decay, ema=args.ema, teacher_temp=args.teacher_temp, student_temp=args.student_temp,
                          center_momentum=args.center_momentum, gram_weight=args.gram_weight)
-    eng = TrainEngine(student, teacher, model_cfg.out_dim, hp, amp_dtype=torch.bfloat16 if args.amp else None)
+    eng = TrainEngine(student, teacher, model_cfg.out_dim, hp, amp_dtype=torch.bfloat16 if args.amp else None,
+                      accumulation_steps=args.accumulation_steps)
     start_step = 0
     if resume_from:
         say(f"resume=true checkpoint={resume_from}")

@@ -630,3 +630,37 @@ def test_full_vit_small_16_step_matches_oracle(dx):
     got16, _ = run(torch.bfloat16)
     assert got16["loss"] == pytest.approx(want["loss"], rel=2e-2)
     assert got16["grad_norm"] == pytest.approx(want["grad_norm"], rel=1e-1)
+
+
+def test_gradient_accumulation_semantics(dx):
+    """accumulation_steps=2 (reference semantics, phase5_big_run.py:1769-1796): with a frozen centre (momentum 1) two
+    identical micro-batches average to the single-batch gradient, so after 2 micro-steps the weights equal one plain step
+    taken with the LR of micro-step 1; no optimiser/EMA/weight change happens after micro-step 0."""
+    ops, arch = dx
+    from dinox.engine import StepHyperParams, TrainEngine
+    kw = dict(img_size=56, patch=14, dim=64, depth=2, heads=2, num_registers=4, scale_aware=True)
+    g = torch.Generator().manual_seed(2)
+    batch, sp = torch.randn(8, 3, 56, 56, generator=g).to(DEV), (torch.rand(8, 3, generator=g) + 0.5).to(DEV)
+
+    def make(accum, hp):
+        torch.manual_seed(9)
+        s_ = arch.DinoStudentTeacher(arch.PatchViT(**kw), 128)
+        torch.nn.init.xavier_uniform_(s_.backbone.scale_embed.mlp[2].weight)
+        t_ = arch.DinoStudentTeacher(arch.PatchViT(**kw), 128)
+        t_.load_state_dict(s_.state_dict())
+        return TrainEngine(s_.to(DEV), t_.to(DEV), 128, hp, accumulation_steps=accum)
+
+    hp2 = StepHyperParams(lr=1e-3, warmup_steps=4, max_steps=20, ema=0.9, center_momentum=1.0)
+    e2 = make(2, hp2)
+    p0 = e2.flat_p.clone()
+    e2.step(batch, sp)
+    assert torch.equal(e2.flat_p, p0) and e2.opt_steps == 0 and torch.equal(e2.flat_t, p0)
+    r = e2.step(batch, sp)
+    assert e2.opt_steps == 1 and e2.step_count == 2 and r["lr"] == pytest.approx(1e-3 * 2 / 4)
+    hp1 = StepHyperParams(lr=1e-3 * 2 / 4, warmup_steps=0, max_steps=None, ema=0.9, center_momentum=1.0)   # constant LR = micro-step 1's
+    e1 = make(1, hp1)
+    e1.step(batch, sp)
+    assert float(e2.last["loss"]) == pytest.approx(float(e1.last["loss"]), rel=1e-6)
+    d = (e2.flat_p - e1.flat_p).abs()
+    assert float((d <= 1e-6 + 1e-4 * e1.flat_p.abs()).double().mean()) > 0.995 and float(d.max()) <= 1.1e-3
+    assert float((e2.flat_t - e1.flat_t).abs().max()) <= 1.2e-4

@@ -193,12 +193,17 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_bf16_tn(GemmParams p, int 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int wr = wv >> 1, wc = wv & 1;
+  // Flattened work id = (split-major, tile-minor), then XCD-remapped: each XCD owns a contiguous run of ids, i.e. all
+  // tiles of ~1.75 K-splits, and they are co-resident (63 workgroups on 64 slots).  The tiles of one split stream the
+  // same K-range, so the A panel shared along tn and the B panel shared along tm are fetched from HBM once per XCD
+  // and re-read from that XCD's L2.  (Tile-major order scattered a split over all 8 private L2s: rocprof FETCH_SIZE
+  // showed 2.8x the algorithmic bytes and the kernel ran at the HBM roofline of that inflated traffic.)
   const int ntile = tiles_m * tiles_n;
-  const int tile = xcd_remap(blockIdx.x, ntile);
+  const int wid = xcd_remap(blockIdx.x, ntile * splits);
+  const int split = wid / ntile, tile = wid % ntile;
   const int tm = tile / tiles_n, tn = tile % tiles_n;
   const int64_t m0 = (int64_t)tm * GB_BM, n0 = (int64_t)tn * GB_BN;
-  const int64_t bz = blockIdx.y / splits;
-  const int split = blockIdx.y % splits;
+  const int64_t bz = blockIdx.y;
   const int64_t kbeg = (int64_t)split * k_per_split;
   int64_t kend = kbeg + k_per_split;
   if (kend > p.K) kend = p.K;
@@ -300,12 +305,17 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_bf16_tn_dma(GemmParams p, 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int wr = wv >> 1, wc = wv & 1;
+  // Flattened work id = (split-major, tile-minor), then XCD-remapped: each XCD owns a contiguous run of ids, i.e. all
+  // tiles of ~1.75 K-splits, and they are co-resident (63 workgroups on 64 slots).  The tiles of one split stream the
+  // same K-range, so the A panel shared along tn and the B panel shared along tm are fetched from HBM once per XCD
+  // and re-read from that XCD's L2.  (Tile-major order scattered a split over all 8 private L2s: rocprof FETCH_SIZE
+  // showed 2.8x the algorithmic bytes and the kernel ran at the HBM roofline of that inflated traffic.)
   const int ntile = tiles_m * tiles_n;
-  const int tile = xcd_remap(blockIdx.x, ntile);
+  const int wid = xcd_remap(blockIdx.x, ntile * splits);
+  const int split = wid / ntile, tile = wid % ntile;
   const int tm = tile / tiles_n, tn = tile % tiles_n;
   const int64_t m0 = (int64_t)tm * GB_BM, n0 = (int64_t)tn * GB_BN;
-  const int64_t bz = blockIdx.y / splits;
-  const int split = blockIdx.y % splits;
+  const int64_t bz = blockIdx.y;
   const int64_t kbeg = (int64_t)split * k_per_split;
   int64_t kend = kbeg + k_per_split;
   if (kend > p.K) kend = p.K;
@@ -464,7 +474,7 @@ int launch_gemm_bf16(const GemmParams& p, hipStream_t st) {
   }
   int64_t kps = ceil_div(ceil_div(p.K, splits), GB_BK) * GB_BK;
   splits = (int)ceil_div(p.K, kps);
-  if ((int64_t)splits * p.batch > 65535) return DINOX_EUNSUPPORTED;
+  if (p.batch > 65535) return DINOX_EUNSUPPORTED;
   if (splits > 1 && !(p.epilogue & DINOX_EPI_ACCUM)) {
     // zero C (rows may be strided by ldc; batch by strideC): contiguous case only, else fall back to 1 split
     if (p.ldc == p.N && (p.batch == 1 || p.strideC == p.M * p.N)) {
@@ -479,7 +489,8 @@ int launch_gemm_bf16(const GemmParams& p, hipStream_t st) {
     hipError_t e = hipMemsetAsync(p.colsum, 0, (size_t)p.M * sizeof(float), st);
     if (e != hipSuccess) return fail((int)e, "gemm_bf16_tn: memset colsum: %s", hipGetErrorString(e));
   }
-  dim3 grid((unsigned)ntile, (unsigned)(p.batch * splits));
+  if (ntile * splits > 0x7fffffff) return DINOX_EUNSUPPORTED;
+  dim3 grid((unsigned)(ntile * splits), (unsigned)p.batch);
   if (v[12] == '_') {  // "gemm_bf16_tn_dma"
     if (p.out_dtype == DINOX_F32)
       hipLaunchKernelGGL((gemm_bf16_tn_dma<DINOX_F32>), grid, dim3(GB_THREADS), lds, st, p, tiles_m, tiles_n, splits, kps);

@@ -6,7 +6,7 @@ namespace dinox {
 int launch_attention_ref_fwd(const void*, void*, float*, int, int, int, int, int, hipStream_t);
 int launch_attention_ref_bwd(const void*, const void*, const void*, const float*, void*, int, int, int, int, int, hipStream_t);
 int launch_attention_bf16_fwd(const void*, void*, float*, int, int, int, int, hipStream_t);   // EUNSUPPORTED if outside envelope
-int launch_attention_bf16_bwd(const void*, const void*, const void*, const float*, void*, int, int, int, int, hipStream_t);
+int launch_attention_bf16_bwd(const void*, const void*, const void*, const float*, void*, float*, int, int, int, int, hipStream_t);
 }  // namespace dinox
 
 using namespace dinox;
@@ -29,13 +29,18 @@ extern "C" int dinox_attention_fwd(const void* qkv, void* o, float* lse, int B, 
   return launch_attention_ref_fwd(qkv, o, lse, B, N, heads, d, dtype, st);
 }
 
-extern "C" int dinox_attention_bwd(const void* d_o, const void* qkv, const void* o, const float* lse, void* dqkv, int B,
-                                   int N, int heads, int d, int dtype, void* stream) {
+extern "C" int64_t dinox_attention_bwd_ws_bytes(int B, int N, int heads) {
+  if (B <= 0 || N <= 0 || heads <= 0) return 0;
+  return (int64_t)B * heads * N * (int64_t)sizeof(float);          // delta[q] = rowsum(dO * O), shared by the two backward kernels
+}
+
+extern "C" int dinox_attention_bwd(const void* d_o, const void* qkv, const void* o, const float* lse, void* dqkv, void* ws,
+                                   int B, int N, int heads, int d, int dtype, void* stream) {
   DX_REQUIRE(d_o && qkv && o && lse && dqkv, DINOX_EINVAL, "attention_bwd: null pointer");
   if (int rc = check_attn("attention_bwd", B, N, heads, d, dtype)) return rc;
   hipStream_t st = as_stream(stream);
   if (dtype == DINOX_BF16) {
-    const int rc = launch_attention_bf16_bwd(d_o, qkv, o, lse, dqkv, B, N, heads, d, st);
+    const int rc = launch_attention_bf16_bwd(d_o, qkv, o, lse, dqkv, (float*)ws, B, N, heads, d, st);
     if (rc != DINOX_EUNSUPPORTED) return rc;
   }
   return launch_attention_ref_bwd(d_o, qkv, o, lse, dqkv, B, N, heads, d, dtype, st);

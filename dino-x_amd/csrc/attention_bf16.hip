@@ -17,6 +17,8 @@
 //   bwd dKV: one wave per 32 keys.     streams query tiles: S = Q . K^T, dP = dO . V^T -> dV += P^T dO, dK += dS^T Q.
 // (two backward kernels recompute S/dP once more than a single fused pass would: 7 instead of 5 tile
 //  products, traded for no cross-wave reduction of dQ; attention is ~8 % of the block's FLOPs.)
+#include <cstdlib>
+
 #include "common.h"
 
 namespace dinox {
@@ -186,12 +188,270 @@ __global__ __launch_bounds__(512) void attn_fwd_bf16(const bf16_t* __restrict__ 
   store_tile(ob, C, q0, N, 32, oacc[1], 1.0f, lane);
 }
 
+// Per-lane constant parts of the fragment addresses.  Tile t of an image starts 4096 B after tile t-1 (32 rows = four 1-KiB
+// row groups; the swizzle terms depend on the row inside the tile only), so address = table entry + 4096*t.
+struct RowAddr {            // A-operand row reads: entry ks
+  int off[4];
+  __device__ __forceinline__ void init(int lane) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) off[ks] = img_off(lane & 31, 2 * ks + (lane >> 5));
+  }
+};
+struct TrAddr {             // permuted-k transposed reads: entry [ss][dt][lo/hi]
+  int off[2][2][2];
+  __device__ __forceinline__ void init(int lane) {
+    const int i = lane & 15, g = lane >> 4, q4 = i >> 2, pp = i & 3;
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const int ch = (dt * 32 >> 3) + 2 * (g & 1) + (pp >> 1);
+        const int r0 = 16 * ss + 4 * (g >> 1) + q4;
+        off[ss][dt][0] = img_off(r0, ch) + 8 * (pp & 1);
+        off[ss][dt][1] = img_off(r0 + 8, ch) + 8 * (pp & 1);
+      }
+  }
+};
+__device__ __forceinline__ bf16x8 rd_rows(const char* img, const RowAddr& a, int ks, int t) {
+  return *reinterpret_cast<const bf16x8*>(img + a.off[ks] + t * 4096);
+}
+__device__ __forceinline__ bf16x8 rd_tr(const char* img, const TrAddr& a, int ss, int dt, int t) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + a.off[ss][dt][0] + t * 4096));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + a.off[ss][dt][1] + t * 4096));
+  s16x8 v;
+  v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+  v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// ------------------------------------------------------------------------------------------ forward, persistent
+typedef __attribute__((address_space(3))) void at_lds_void;
+typedef __attribute__((address_space(1))) const void at_gbl_void;
+
+// LDS-DMA of one [npad][64] image: wave-instruction `blk` fills rows 8*blk .. 8*blk+7 (1 KiB, lane-linear destination); the
+// img_off() placement is produced by permuting the per-lane SOURCE address.  Rows >= n_valid re-read row n_valid-1 (finite
+// data; every consumer masks those keys/queries), so no address leaves the tensor.
+__device__ __forceinline__ void dma_image(char* __restrict__ img, const bf16_t* __restrict__ src, int64_t row_stride, int n_valid,
+                                          int npad, int wv, int nw, int lane) {
+  const int half = lane >> 5, rr = (lane >> 2) & 7, slot = lane & 3;
+  for (int blk = wv; blk < (npad >> 3); blk += nw) {
+    int row = 8 * blk + rr;
+    const int ch = (half << 2) | (slot ^ ((row >> 2) & 3));
+    row = row < n_valid ? row : n_valid - 1;
+    __builtin_amdgcn_global_load_lds((at_gbl_void*)(src + (int64_t)row * row_stride + ch * 8), (at_lds_void*)(img + blk * 1024), 16, 0, 0);
+  }
+}
+
+// One workgroup per CU walks (batch, head) pairs.  K and V images are double-buffered and filled by LDS-DMA for pair i+1
+// while the MFMAs of pair i run, so HBM latency and the image fill never sit on the critical path (the one-pair-per-
+// workgroup kernel spends about half its time filling LDS with nothing to overlap).  Wave w owns query blocks w, w+nw, ...
+template <int NKT>   // NKT > 0: one pass, all NKT score tiles stay in registers (16*NKT VGPRs);  NKT == 0: two passes, any nkt
+__global__ __launch_bounds__(512) void attn_fwd_bf16_persist(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
+                                                             float* __restrict__ lse, int N, int heads, int nkt, float sc,
+                                                             int npairs) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+  const int C = heads * AT_D;
+  const int64_t rs = 3 * (int64_t)C;
+  const int npad = nkt * 32, img_bytes = npad * 128;
+  float* inv_s = reinterpret_cast<float*>(smem + 4 * img_bytes) + wv * 32;
+  const int hl = lane >> 5;
+  int pair = blockIdx.x;
+  if (pair >= npairs) return;
+
+  auto base_of = [&](int pr) { return qkv + (int64_t)(pr / heads) * N * rs + (pr % heads) * AT_D; };
+  auto issue = [&](int pr, int buf) {
+    const bf16_t* base = base_of(pr);
+    dma_image(smem + (2 * buf) * img_bytes, base + C, rs, N, npad, wv, nw, lane);
+    dma_image(smem + (2 * buf + 1) * img_bytes, base + 2 * C, rs, N, npad, wv, nw, lane);
+  };
+  auto q_frags = [&](bf16x8 (&f)[4], int pr, int qb) {
+    int qrow = qb * 32 + (lane & 31);
+    qrow = qrow < N ? qrow : N - 1;
+    load_row_frags(f, base_of(pr) + (int64_t)qrow * rs, lane);
+  };
+
+  bf16x8 qnext[4];
+  q_frags(qnext, pair, wv);                 // prefetched one pair ahead, together with that pair's images
+  issue(pair, 0);
+  for (int it = 0; pair < npairs; pair += gridDim.x, ++it) {
+    const int buf = it & 1;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = qnext[ks];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my DMA pieces (and Q fragments) for this pair have landed
+    __builtin_amdgcn_s_barrier();                         // everyone's pieces landed; everyone is done with the other buffer
+    __builtin_amdgcn_sched_barrier(0);
+    const int nxt = pair + gridDim.x;
+    if (nxt < npairs) {
+      q_frags(qnext, nxt, wv);
+      issue(nxt, buf ^ 1);
+    }
+    const char* kimg = smem + (2 * buf) * img_bytes;
+    const char* vimg = kimg + img_bytes;
+    const int b = pair / heads, hh = pair % heads;
+    for (int qb = wv; qb * 32 < N; qb += nw) {
+      if (qb != wv) q_frags(qf, pair, qb);               // more query blocks than waves (N > 256): fetched on demand
+      const int q0 = qb * 32;
+      // Key tile kt sits 4096 B after tile kt-1 in the image (32 rows = four 1-KiB row groups, swizzle terms unchanged), so
+      // every fragment address is a per-lane constant plus kt*4096: computed once here, not per tile.
+      const char* kr[4];
+      const char* vt[2][2][2];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) kr[ks] = kimg + img_off(lane & 31, 2 * ks + hl);
+      {
+        const int i = lane & 15, g = lane >> 4, q4 = i >> 2, pp = i & 3;
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            const int ch = (dt * 32 >> 3) + 2 * (g & 1) + (pp >> 1);
+            const int r0 = 16 * ss + 4 * (g >> 1) + q4;
+            vt[ss][dt][0] = vimg + img_off(r0, ch) + 8 * (pp & 1);
+            vt[ss][dt][1] = vimg + img_off(r0 + 8, ch) + 8 * (pp & 1);
+          }
+      }
+      const float c2 = sc * 1.4426950408889634f;         // exp(x*sc - m) = exp2(x*c2 - m*log2e)
+      f32x16 oacc[2];
+      zero16(oacc[0]);
+      zero16(oacc[1]);
+      float sum = 0.f, mx;
+      if constexpr (NKT > 0) {
+        // one pass: every S^T tile is produced first (independent accumulators: the matrix pipe never waits), the row
+        // maximum is taken over registers, and each tile's exp2 / bf16 pack feeds its PV MFMAs while later tiles are
+        // still being exponentiated (straight-line code: MFMA and VALU of different tiles overlap inside the wave)
+        f32x16 st[NKT];
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+          zero16(st[kt]);
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks)
+            st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(kr[ks] + kt * 4096), qf[ks], st[kt], 0, 0, 0);
+        }
+        mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            if (kt == NKT - 1 && !(kt * 32 + acc_row(e, hl) < N)) st[kt][e] = -INFINITY;   // padded keys live in the last tile only
+            mx = fmaxf(mx, st[kt][e]);
+          }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mx2 = mx * c2;
+        mx *= sc;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const float pr = __builtin_amdgcn_exp2f(st[kt][e] * c2 - mx2);      // exp2(-inf) = 0 for padded keys
+            st[kt][e] = pr;
+            sum += pr;
+          }
+#pragma unroll
+          for (int ss = 0; ss < 2; ++ss) {
+            const bf16x8 pa = acc_as_a(st[kt], ss);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+              const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vt[ss][dt][0] + kt * 4096));
+              const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vt[ss][dt][1] + kt * 4096));
+              s16x8 v;
+              v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+              v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+              oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, __builtin_bit_cast(bf16x8, v), oacc[dt], 0, 0, 0);
+            }
+          }
+        }
+      } else {
+      mx = -INFINITY;
+#pragma unroll 1
+      for (int kt = 0; kt < nkt; ++kt) {
+        f32x16 st;
+        zero16(st);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(kr[ks] + kt * 4096), qf[ks], st, 0, 0, 0);
+        if (kt == nkt - 1) {                              // only the last tile can hold padded keys
+#pragma unroll
+          for (int e = 0; e < 16; ++e) mx = fmaxf(mx, kt * 32 + acc_row(e, hl) < N ? st[e] : -INFINITY);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) mx = fmaxf(mx, st[e]);
+        }
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mx2 = mx * c2;
+      mx *= sc;
+#pragma unroll 1
+      for (int kt = 0; kt < nkt; ++kt) {
+        f32x16 st;
+        zero16(st);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(kr[ks] + kt * 4096), qf[ks], st, 0, 0, 0);
+        if (kt == nkt - 1) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const float pr = kt * 32 + acc_row(e, hl) < N ? __builtin_amdgcn_exp2f(st[e] * c2 - mx2) : 0.f;
+            st[e] = pr;
+            sum += pr;
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const float pr = __builtin_amdgcn_exp2f(st[e] * c2 - mx2);
+            st[e] = pr;
+            sum += pr;
+          }
+        }
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+          const bf16x8 pa = acc_as_a(st, ss);
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vt[ss][dt][0] + kt * 4096));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vt[ss][dt][1] + kt * 4096));
+            s16x8 v;
+            v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+            v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+            oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, __builtin_bit_cast(bf16x8, v), oacc[dt], 0, 0, 0);
+          }
+        }
+      }
+      }
+      sum += __shfl_xor(sum, 32, 64);
+      if (hl == 0) {
+        inv_s[lane] = 1.0f / sum;
+        if (q0 + lane < N) lse[((int64_t)b * heads + hh) * N + q0 + lane] = mx + __logf(sum);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 iv = *reinterpret_cast<const float4*>(inv_s + 8 * g + 4 * hl);
+        const float ivv[4] = {iv.x, iv.y, iv.z, iv.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          oacc[0][4 * g + r] *= ivv[r];
+          oacc[1][4 * g + r] *= ivv[r];
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      bf16_t* ob = o + (int64_t)b * N * C + hh * AT_D;
+      store_tile(ob, C, q0, N, 0, oacc[0], 1.0f, lane);
+      store_tile(ob, C, q0, N, 32, oacc[1], 1.0f, lane);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------ backward: dQ
 __global__ __launch_bounds__(512) void attn_bwd_dq_bf16(const bf16_t* __restrict__ d_o, const bf16_t* __restrict__ qkv,
                                                         const bf16_t* __restrict__ o, const float* __restrict__ lse,
-                                                        bf16_t* __restrict__ dqkv, int N, int heads, int nkt, float sc) {
+                                                        bf16_t* __restrict__ dqkv, float* __restrict__ delta_ws, int N, int heads,
+                                                        int nkt, float sc) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = blockIdx.x / heads, hh = blockIdx.x % heads;
   const int C = heads * AT_D;
   const int64_t rs = 3 * (int64_t)C;
@@ -199,11 +459,12 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_bf16(const bf16_t* __restrict
   const int npad = nkt * 32;
   char* kimg = smem;
   char* vimg = smem + npad * 128;
-  load_image(kimg, base + C, rs, N, npad);
-  load_image(vimg, base + 2 * C, rs, N, npad);
-  __syncthreads();
+  // K and V images by LDS-DMA (all pieces in flight at once; a register-staged fill loop serialises one HBM round trip per
+  // iteration), the wave's own Q / dO / O rows by ordinary loads issued alongside
+  dma_image(kimg, base + C, rs, N, npad, wv, nw, lane);
+  dma_image(vimg, base + 2 * C, rs, N, npad, wv, nw, lane);
   const int qb = blockIdx.y * nw + wv;
-  if (qb * 32 >= N) return;
+  const bool active = qb * 32 < N;                                  // wave-uniform
   const int q0 = qb * 32, hl = lane >> 5;
   int qrow = q0 + (lane & 31);
   if (qrow >= N) qrow = N - 1;
@@ -212,38 +473,52 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_bf16(const bf16_t* __restrict
   load_row_frags(qf, base + (int64_t)qrow * rs, lane);
   load_row_frags(dof, d_o + orow, lane);
   load_row_frags(of, o + orow, lane);
+  const float L = lse[((int64_t)b * heads + hh) * N + qrow];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  if (!active) return;
   float delta = 0.f;
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
     for (int j = 0; j < 8; ++j) delta += (float)dof[ks][j] * (float)of[ks][j];
   delta += __shfl_xor(delta, 32, 64);
-  const float L = lse[((int64_t)b * heads + hh) * N + qrow];
+  if (hl == 0 && q0 + lane < N) delta_ws[((int64_t)b * heads + hh) * N + q0 + lane] = delta;   // re-used by the dK/dV kernel
 
   f32x16 dq[2];
   zero16(dq[0]);
   zero16(dq[1]);
+  RowAddr ra;
+  TrAddr ta;
+  ra.init(lane);
+  ta.init(lane);
+  const float c2 = sc * 1.4426950408889634f, L2 = L * 1.4426950408889634f;     // exp(s*sc - L) = exp2(s*c2 - L*log2e)
+#pragma unroll 1
   for (int kt = 0; kt < nkt; ++kt) {
     f32x16 st, dp;
     zero16(st);
     zero16(dp);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(kimg, kt * 32, ks, lane), qf[ks], st, 0, 0, 0);
-      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(vimg, kt * 32, ks, lane), dof[ks], dp, 0, 0, 0);
+      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_rows(kimg, ra, ks, kt), qf[ks], st, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_rows(vimg, ra, ks, kt), dof[ks], dp, 0, 0, 0);
     }
+    if (kt == nkt - 1) {                                               // padded keys only in the last tile
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int key = kt * 32 + acc_row(e, hl);
-      const float p = __expf(st[e] * sc - L);
-      st[e] = key < N ? p * (dp[e] - delta) * sc : 0.f;             // dS^T (scaled), padded keys contribute nothing
+      for (int e = 0; e < 16; ++e) {
+        const float p = __builtin_amdgcn_exp2f(st[e] * c2 - L2);
+        st[e] = kt * 32 + acc_row(e, hl) < N ? p * (dp[e] - delta) * sc : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) st[e] = __builtin_amdgcn_exp2f(st[e] * c2 - L2) * (dp[e] - delta) * sc;   // dS^T (scaled)
     }
 #pragma unroll
     for (int ss = 0; ss < 2; ++ss) {
       const bf16x8 a = acc_as_a(st, ss);
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-        dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, frag_tr_perm(kimg, kt * 32, ss, dt * 32, lane), dq[dt], 0, 0, 0);
+      for (int dt = 0; dt < 2; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, rd_tr(kimg, ta, ss, dt, kt), dq[dt], 0, 0, 0);
     }
   }
   bf16_t* dqb = dqkv + (int64_t)b * N * rs + hh * AT_D;
@@ -253,79 +528,78 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_bf16(const bf16_t* __restrict
 
 // ------------------------------------------------------------------------------------------ backward: dK, dV
 __global__ __launch_bounds__(512) void attn_bwd_dkv_bf16(const bf16_t* __restrict__ d_o, const bf16_t* __restrict__ qkv,
-                                                         const bf16_t* __restrict__ o, const float* __restrict__ lse,
+                                                         const float* __restrict__ lse, const float* __restrict__ delta_ws,
                                                          bf16_t* __restrict__ dqkv, int N, int heads, int nqt, float sc) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = blockIdx.x / heads, hh = blockIdx.x % heads;
   const int C = heads * AT_D;
   const int64_t rs = 3 * (int64_t)C;
   const bf16_t* base = qkv + (int64_t)b * N * rs + hh * AT_D;
   const bf16_t* dob = d_o + (int64_t)b * N * C + hh * AT_D;
-  const bf16_t* ob = o + (int64_t)b * N * C + hh * AT_D;
   const int npad = nqt * 32;
   char* qimg = smem;
   char* doimg = smem + npad * 128;
-  float* lse_s = reinterpret_cast<float*>(smem + 2 * npad * 128);
-  float* del_s = lse_s + npad;
-  load_image(qimg, base, rs, N, npad);
-  // dO image + delta[q] = sum_d dO*O in the same pass: 8 consecutive threads own the 8 chunks of one row
-  for (int idx = threadIdx.x; idx < npad * 8; idx += blockDim.x) {
-    const int r = idx >> 3, ch = idx & 7;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    float part = 0.f;
-    if (r < N) {
-      v = *reinterpret_cast<const uint4*>(dob + (int64_t)r * C + ch * 8);
-      const uint4 w = *reinterpret_cast<const uint4*>(ob + (int64_t)r * C + ch * 8);
-      const bf16_t* a = reinterpret_cast<const bf16_t*>(&v);
-      const bf16_t* c = reinterpret_cast<const bf16_t*>(&w);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) part += bf16_to_f32(a[j]) * bf16_to_f32(c[j]);
-    }
-    *reinterpret_cast<uint4*>(doimg + img_off(r, ch)) = v;
-    part += __shfl_xor(part, 1, 64);
-    part += __shfl_xor(part, 2, 64);
-    part += __shfl_xor(part, 4, 64);
-    if (ch == 0) {
-      del_s[r] = part;
-      lse_s[r] = r < N ? lse[((int64_t)b * heads + hh) * N + r] : INFINITY;   // exp(x - inf) = 0 for padded queries
-    }
+  float* lse2_s = reinterpret_cast<float*>(smem + 2 * npad * 128);     // lse * log2(e), query-indexed
+  float* del_s = lse2_s + npad;
+  dma_image(qimg, base, rs, N, npad, wv, nw, lane);
+  dma_image(doimg, dob, C, N, npad, wv, nw, lane);
+  for (int r = threadIdx.x; r < npad; r += blockDim.x) {              // per-query statistics (delta comes from the dQ kernel)
+    const int64_t si = ((int64_t)b * heads + hh) * N + r;
+    lse2_s[r] = r < N ? lse[si] * 1.4426950408889634f : INFINITY;    // exp2(x - inf) = 0 for padded queries
+    del_s[r] = r < N ? delta_ws[si] : 0.f;
   }
-  __syncthreads();
   const int kb = blockIdx.y * nw + wv;
-  if (kb * 32 >= N) return;
   const int k0 = kb * 32, hl = lane >> 5;
   int krow = k0 + (lane & 31);
   if (krow >= N) krow = N - 1;
   bf16x8 kf[4], vf[4];
   load_row_frags(kf, base + (int64_t)krow * rs + C, lane);
   load_row_frags(vf, base + (int64_t)krow * rs + 2 * C, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                                                   // DMA pieces + the LDS statistics of every wave
+  if (kb * 32 >= N) return;
 
   f32x16 dk[2], dv[2];
   zero16(dk[0]); zero16(dk[1]); zero16(dv[0]); zero16(dv[1]);
+  RowAddr ra;
+  TrAddr ta;
+  ra.init(lane);
+  ta.init(lane);
+  const float c2 = sc * 1.4426950408889634f;
+#pragma unroll 1
   for (int qt = 0; qt < nqt; ++qt) {
     f32x16 st, dp;
     zero16(st);
     zero16(dp);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(qimg, qt * 32, ks, lane), kf[ks], st, 0, 0, 0);   // S[q][key]
-      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(doimg, qt * 32, ks, lane), vf[ks], dp, 0, 0, 0);  // dP[q][key]
+      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_rows(qimg, ra, ks, qt), kf[ks], st, 0, 0, 0);     // S[q][key]
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_rows(doimg, ra, ks, qt), vf[ks], dp, 0, 0, 0);    // dP[q][key]
     }
+    // per-row statistics of the 16 query rows this lane holds: 4 consecutive rows per register group -> one 16-B LDS read
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int q = qt * 32 + acc_row(e, hl);
-      const float p = __expf(st[e] * sc - lse_s[q]);
-      st[e] = p;                                                   // P
-      dp[e] = p * (dp[e] - del_s[q]) * sc;                         // dS (scaled)
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int q = qt * 32 + 8 * g4 + 4 * hl;
+      const float4 l4 = *reinterpret_cast<const float4*>(lse2_s + q);
+      const float4 d4 = *reinterpret_cast<const float4*>(del_s + q);
+      const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dvv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int e = 4 * g4 + r;
+        const float p = __builtin_amdgcn_exp2f(st[e] * c2 - lv[r]);      // lse2 = lse*log2e; +inf for padded queries -> p = 0
+        st[e] = p;                                                   // P
+        dp[e] = p * (dp[e] - dvv[r]) * sc;                           // dS (scaled)
+      }
     }
 #pragma unroll
     for (int ss = 0; ss < 2; ++ss) {
       const bf16x8 pa = acc_as_a(st, ss), da = acc_as_a(dp, ss);
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
-        dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, frag_tr_perm(doimg, qt * 32, ss, dt * 32, lane), dv[dt], 0, 0, 0);
-        dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, frag_tr_perm(qimg, qt * 32, ss, dt * 32, lane), dk[dt], 0, 0, 0);
+        dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, rd_tr(doimg, ta, ss, dt, qt), dv[dt], 0, 0, 0);
+        dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, rd_tr(qimg, ta, ss, dt, qt), dk[dt], 0, 0, 0);
       }
     }
   }
@@ -356,6 +630,24 @@ int launch_attention_bf16_fwd(const void* qkv, void* o, float* lse, int B, int N
   int nblk, nwg, waves;
   geometry(N, nblk, nwg, waves);
   const float sc = 1.0f / sqrtf((float)d);
+  {
+    const int nw = nblk < 8 ? nblk : 8;
+    const size_t lds = (size_t)4 * nblk * 32 * 128 + 8 * 32 * sizeof(float);
+    static const bool off = getenv("DINOX_ATTN_NO_PERSIST") != nullptr;
+    if (lds <= 160 * 1024 && !off) {
+      const int npairs = B * heads;
+      const int nwgp = npairs < 256 ? npairs : 256;                 // one resident workgroup per CU
+#define PFWD(NKT)                                                                                                                  \
+  do {                                                                                                                             \
+    if (int rc = allow_lds(attn_fwd_bf16_persist<NKT>, lds)) return fail(rc, "attention_fwd: cannot reserve %zu B of LDS", lds);   \
+    hipLaunchKernelGGL((attn_fwd_bf16_persist<NKT>), dim3(nwgp), dim3(nw * 64), lds, st, (const bf16_t*)qkv, (bf16_t*)o, lse, N,    \
+                       heads, nblk, sc, npairs);                                                                                   \
+  } while (0)
+      if (nblk == 7) PFWD(7); else if (nblk == 1) PFWD(1); else if (nblk == 2) PFWD(2); else PFWD(0);   // 8 tiles would spill: two-pass form
+#undef PFWD
+      return check_launch("attention_bf16_fwd_persist");
+    }
+  }
   dim3 grid((unsigned)(B * heads), (unsigned)nwg), block((unsigned)(waves * 64));
 #define FWD(NKT)                                                                                                   \
   do {                                                                                                             \
@@ -368,8 +660,9 @@ int launch_attention_bf16_fwd(const void* qkv, void* o, float* lse, int B, int N
   return check_launch("attention_bf16_fwd");
 }
 
-int launch_attention_bf16_bwd(const void* d_o, const void* qkv, const void* o, const float* lse, void* dqkv, int B, int N,
-                              int heads, int d, hipStream_t st) {
+int launch_attention_bf16_bwd(const void* d_o, const void* qkv, const void* o, const float* lse, void* dqkv, float* ws, int B,
+                              int N, int heads, int d, hipStream_t st) {
+  if (!ws) return DINOX_EUNSUPPORTED;
   if (d != AT_D || N > 544 || ((uintptr_t)qkv & 15) || ((uintptr_t)o & 15) || ((uintptr_t)d_o & 15)) return DINOX_EUNSUPPORTED;
   int nblk, nwg, waves;
   geometry(N, nblk, nwg, waves);
@@ -380,8 +673,8 @@ int launch_attention_bf16_bwd(const void* d_o, const void* qkv, const void* o, c
   if (int rc = allow_lds(attn_bwd_dq_bf16, lds1)) return fail(rc, "attention_bwd: cannot reserve %zu B of LDS", lds1);
   if (int rc = allow_lds(attn_bwd_dkv_bf16, lds2)) return fail(rc, "attention_bwd: cannot reserve %zu B of LDS", lds2);
   hipLaunchKernelGGL(attn_bwd_dq_bf16, grid, block, lds1, st, (const bf16_t*)d_o, (const bf16_t*)qkv, (const bf16_t*)o, lse,
-                     (bf16_t*)dqkv, N, heads, nblk, sc);
-  hipLaunchKernelGGL(attn_bwd_dkv_bf16, grid, block, lds2, st, (const bf16_t*)d_o, (const bf16_t*)qkv, (const bf16_t*)o, lse,
+                     (bf16_t*)dqkv, ws, N, heads, nblk, sc);
+  hipLaunchKernelGGL(attn_bwd_dkv_bf16, grid, block, lds2, st, (const bf16_t*)d_o, (const bf16_t*)qkv, lse, (const float*)ws,
                      (bf16_t*)dqkv, N, heads, nblk, sc);
   return check_launch("attention_bf16_bwd");
 }

@@ -292,7 +292,9 @@ def attention_bwd(do: Tensor, qkv: Tensor, o: Tensor, lse: Tensor, heads: int) -
     B, N, C3 = qkv.shape
     d = C3 // 3 // heads
     dqkv = torch.empty_like(qkv)
-    check(lib.dinox_attention_bwd(_p(do), _p(qkv), _p(o), _p(lse), _p(dqkv), B, N, heads, d, _code(qkv.dtype), _stream()), "dinox_attention_bwd")
+    ws = torch.empty(lib.dinox_attention_bwd_ws_bytes(B, N, heads), dtype=torch.uint8, device=qkv.device)
+    check(lib.dinox_attention_bwd(_p(do), _p(qkv), _p(o), _p(lse), _p(dqkv), _p(ws), B, N, heads, d, _code(qkv.dtype), _stream()),
+          "dinox_attention_bwd")
     return dqkv
 
 

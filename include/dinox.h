@@ -124,11 +124,12 @@ int dinox_layernorm_bwd(const void* dy, const float* x, const float* w, const fl
  * F.scaled_dot_product_attention + transpose/reshape of zoo/arch.py:45-52 (scale 1/sqrt(d), no mask).
  * qkv is the packed output of the qkv Linear, [B][N][3][heads][d]; o is [B][N][heads*d];
  * lse is the per-row log-sum-exp of the scaled scores, [B][heads][N] fp32 (saved for backward).
- * bwd recomputes P from lse (flash style); dqkv has the layout of qkv.
+ * bwd recomputes P from lse (flash style); dqkv has the layout of qkv; ws: dinox_attention_bwd_ws_bytes() bytes.
  * ------------------------------------------------------------------------------------------ */
 int dinox_attention_fwd(const void* qkv, void* o, float* lse, int B, int N, int heads, int d, int dtype,
                         void* stream);
-int dinox_attention_bwd(const void* d_o, const void* qkv, const void* o, const float* lse, void* dqkv,
+int64_t dinox_attention_bwd_ws_bytes(int B, int N, int heads);
+int dinox_attention_bwd(const void* d_o, const void* qkv, const void* o, const float* lse, void* dqkv, void* ws,
                         int B, int N, int heads, int d, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------

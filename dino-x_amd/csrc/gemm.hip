@@ -73,7 +73,7 @@ extern "C" int dinox_gemm(const dinox_gemm_args* a, void* stream) {
     // shape/layout outside the MFMA-bf16 kernel's envelope: exact-fp32 MFMA on the bf16 values.
   }
   if (p.colsum) {                                    // A is stored [K][M]: its column sums are the wanted vector
-    const int rc = dinox_colsum(p.A, p.colsum, p.K, p.M, p.lda, p.in_dtype, 0, stream);
+    const int rc = dinox_colsum(p.A, p.colsum, p.K, p.M, p.lda, p.in_dtype, (p.epilogue & DINOX_EPI_ACCUM) ? 1 : 0, stream);
     if (rc) return rc;
   }
   return launch_gemm_f32(p, st);

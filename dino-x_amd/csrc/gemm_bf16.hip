@@ -485,7 +485,7 @@ int launch_gemm_bf16(const GemmParams& p, hipStream_t st) {
       kps = ceil_div(p.K, GB_BK) * GB_BK;
     }
   }
-  if (p.colsum) {
+  if (p.colsum && !(p.epilogue & DINOX_EPI_ACCUM)) {     // with ACCUM the column sums are added to what colsum holds, like C
     hipError_t e = hipMemsetAsync(p.colsum, 0, (size_t)p.M * sizeof(float), st);
     if (e != hipSuccess) return fail((int)e, "gemm_bf16_tn: memset colsum: %s", hipGetErrorString(e));
   }

@@ -107,6 +107,42 @@ __global__ __launch_bounds__(256, (GG_BM == 256 ? 2 : (GG_BK == 64 ? 2 : 3))) vo
 
   const int nk = (int)(p.K / GG_BK);
   const int frow = lane & 31, fh = lane >> 5;
+
+  // ---- epilogue operand prefetch.  The fused epilogue reads one more tile from HBM (GELU' input for DGELU, the fp32 residual for
+  // RES); fetched where it is used, that read's full latency is exposed once per pass of every tile (rocprof: +130 us on the dgelu
+  // product).  The loads of pass 0 are issued here, ahead of the K loop (older than every staging DMA, so the counted vmcnt waits below
+  // still cover what they must), the loads of pass 1 right before pass 0 is parked.
+  constexpr int PASSES = (STAGES * STAGE_BYTES >= WAVES * WROWS * 256) ? 1 : WM;    // one pass, or one 32-row MFMA tile row per pass
+  constexpr int PROWS = WROWS / PASSES;
+  constexpr int NIT = PROWS / 8;                  // row-iterations of one pass (a lane owns 8 consecutive columns of one row in each)
+  constexpr bool PF_AUX = ACT == GG_DGELU, PF_RES = RES;
+  const int c8 = lane & 7;
+  const int64_t n = n0 + wc * 64 + c8 * 8;
+  const bool n_ok = n < p.N;                               // N % 8 == 0: a lane's 8 columns are all in or all out
+  const int64_t n_ld = n_ok ? n : 0;
+  float4 pf_aux[PF_AUX ? NIT : 1][OUT_DT == DINOX_BF16 ? 1 : 2];     // bf16 aux: 16 B per row-iteration; fp32: 32 B
+  float4 pf_res[PF_RES ? NIT : 1][2];
+  auto prefetch = [&](int ps) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      int64_t m = m0 + wr * WROWS + ps * PROWS + it * 8 + (lane >> 3);
+      m = m < p.M ? m : p.M - 1;                           // rows past M are loaded (valid address) and never stored
+      if (PF_AUX) {
+        const int64_t ai = bz * p.M * p.ldaux + m * p.ldaux + n_ld;
+        if (OUT_DT == DINOX_BF16) pf_aux[it][0] = *reinterpret_cast<const float4*>((const bf16_t*)p.aux + ai);
+        else {
+          pf_aux[it][0] = *reinterpret_cast<const float4*>((const float*)p.aux + ai);
+          pf_aux[it][OUT_DT == DINOX_BF16 ? 0 : 1] = *reinterpret_cast<const float4*>((const float*)p.aux + ai + 4);
+        }
+      }
+      if (PF_RES) {
+        const float* rp = p.residual + bz * p.M * p.ldr + m * p.ldr + n_ld;
+        pf_res[it][0] = *reinterpret_cast<const float4*>(rp);
+        pf_res[it][1] = *reinterpret_cast<const float4*>(rp + 4);
+      }
+    }
+  };
+  if (PF_AUX || PF_RES) prefetch(0);
   auto compute = [&](int buf) {
     const char* sa = smem + buf * STAGE_BYTES;
     const char* sb = sa + A_TILE;
@@ -162,12 +198,7 @@ __global__ __launch_bounds__(256, (GG_BM == 256 ? 2 : (GG_BK == 64 ? 2 : 3))) vo
   // ---- epilogue: park the wave's accumulator block in LDS (row = 256 B, 16-B chunks XOR (row&15)) and re-read it by
   // rows.  With BK = 64 the four waves park 64 rows each at once (64 KiB = both stages); with BK = 32 the stages are
   // 32 KiB, so each wave parks its two 32-row halves one after the other.
-  constexpr int PASSES = (STAGES * STAGE_BYTES >= WAVES * WROWS * 256) ? 1 : WM;    // one pass, or one 32-row MFMA tile row per pass
-  constexpr int PROWS = WROWS / PASSES;
   char* park = smem + wv * (PROWS * 256);
-  const int c8 = lane & 7;
-  const int64_t n = n0 + wc * 64 + c8 * 8;
-  const bool n_ok = n < p.N;                               // N % 8 == 0: a lane's 8 columns are all in or all out
   float bias[8];
 #pragma unroll
   for (int u = 0; u < 8; ++u) bias[u] = 0.f;
@@ -193,6 +224,22 @@ __global__ __launch_bounds__(256, (GG_BM == 256 ? 2 : (GG_BK == 64 ? 2 : 3))) vo
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    float4 cur_aux[PF_AUX ? NIT : 1][OUT_DT == DINOX_BF16 ? 1 : 2];
+    float4 cur_res[PF_RES ? NIT : 1][2];
+    if (PF_AUX || PF_RES) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        if (PF_AUX) {
+          cur_aux[it][0] = pf_aux[it][0];
+          if (OUT_DT != DINOX_BF16) cur_aux[it][OUT_DT == DINOX_BF16 ? 0 : 1] = pf_aux[it][OUT_DT == DINOX_BF16 ? 0 : 1];
+        }
+        if (PF_RES) {
+          cur_res[it][0] = pf_res[it][0];
+          cur_res[it][1] = pf_res[it][1];
+        }
+      }
+      if (ps + 1 < PASSES) prefetch(ps + 1);
+    }
 #pragma unroll
     for (int it = 0; it < PROWS / 8; ++it) {
       const int row = it * 8 + (lane >> 3);
@@ -235,14 +282,17 @@ __global__ __launch_bounds__(256, (GG_BM == 256 ? 2 : (GG_BK == 64 ? 2 : 3))) vo
         }
       }
       if (ACT == GG_DGELU) {
-        const int64_t ai = bz * p.M * p.ldaux + m * p.ldaux + n;
         float x[8];
         if (OUT_DT == DINOX_BF16) {
-          const s16x8 pk = *reinterpret_cast<const s16x8*>((const bf16_t*)p.aux + ai);
+          const float4 raw = cur_aux[it][0];
+          const uint32_t w[4] = {__float_as_uint(raw.x), __float_as_uint(raw.y), __float_as_uint(raw.z), __float_as_uint(raw.w)};
 #pragma unroll
-          for (int u = 0; u < 8; ++u) x[u] = bf16_to_f32((bf16_t)pk[u]);
+          for (int u = 0; u < 4; ++u) {
+            x[2 * u] = __uint_as_float(w[u] << 16);
+            x[2 * u + 1] = __uint_as_float(w[u] & 0xffff0000u);
+          }
         } else {
-          const float4 x0 = *reinterpret_cast<const float4*>((const float*)p.aux + ai), x1 = *reinterpret_cast<const float4*>((const float*)p.aux + ai + 4);
+          const float4 x0 = cur_aux[it][0], x1 = cur_aux[it][OUT_DT == DINOX_BF16 ? 0 : 1];
           x[0] = x0.x; x[1] = x0.y; x[2] = x0.z; x[3] = x0.w; x[4] = x1.x; x[5] = x1.y; x[6] = x1.z; x[7] = x1.w;
         }
         if (p.epilogue & DINOX_EPI_AUXGRAD) {
@@ -254,8 +304,7 @@ __global__ __launch_bounds__(256, (GG_BM == 256 ? 2 : (GG_BK == 64 ? 2 : 3))) vo
         }
       }
       if (RES) {
-        const float* rp = p.residual + bz * p.M * p.ldr + m * p.ldr + n;
-        const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
+        const float4 r0 = cur_res[it][0], r1 = cur_res[it][1];
         v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
         v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
       }

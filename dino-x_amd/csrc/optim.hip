@@ -92,6 +92,36 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __rest
   }
 }
 
+// The same for every matrix of a parameter arena in ONE launch.  table[i] = {element offset in both arenas, R, C, first tile};
+// a workgroup finds its matrix by bisection over the first-tile column and transposes one 32x32 tile of it.
+__global__ __launch_bounds__(256) void cast_transpose_multi_kernel(const float* __restrict__ src_base, bf16_t* __restrict__ dst_base,
+                                                                   const int64_t* __restrict__ table, int n_mats) {
+  __shared__ float tile[32][33];
+  const int64_t bid = blockIdx.x;
+  int lo = 0, hi = n_mats - 1;
+  while (lo < hi) {                                   // last i with table[i].first_tile <= bid
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[4 * mid + 3] <= bid) lo = mid; else hi = mid - 1;
+  }
+  const int64_t off = table[4 * lo];
+  const int R = (int)table[4 * lo + 1], C = (int)table[4 * lo + 2];
+  const int t = (int)(bid - table[4 * lo + 3]);
+  const int tiles_c = (C + 31) >> 5;
+  const int c0 = (t % tiles_c) * 32, r0 = (t / tiles_c) * 32;
+  const float* src = src_base + off;
+  bf16_t* dst = dst_base + off;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8) {
+    const int r = r0 + j, c = c0 + tx;
+    tile[j][tx] = (r < R && c < C) ? src[(int64_t)r * C + c] : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int c = c0 + j, r = r0 + tx;
+    if (c < C && r < R) dst[(int64_t)c * R + r] = f32_to_bf16(tile[tx][j]);
+  }
+}
+
 __global__ __launch_bounds__(256) void gelu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = gelu_erf(x[i]);
 }
@@ -148,6 +178,16 @@ extern "C" int dinox_cast_transpose_bf16(const float* src, void* dst, int R, int
   dim3 grid((unsigned)ceil_div(C, 32), (unsigned)ceil_div(R, 32));
   hipLaunchKernelGGL(cast_transpose_kernel, grid, dim3(256), 0, as_stream(stream), src, (bf16_t*)dst, R, C);
   return check_launch("cast_transpose_bf16");
+}
+
+extern "C" int dinox_cast_transpose_bf16_multi(const float* src_base, void* dst_base, const int64_t* table, int n_mats,
+                                               int64_t total_tiles, void* stream) {
+  DX_REQUIRE(src_base && dst_base && table, DINOX_EINVAL, "cast_transpose_bf16_multi: null pointer");
+  DX_REQUIRE(n_mats > 0 && total_tiles > 0 && total_tiles <= 0x7fffffff, DINOX_EINVAL, "cast_transpose_bf16_multi: n_mats=%d tiles=%lld",
+             n_mats, (long long)total_tiles);
+  hipLaunchKernelGGL(cast_transpose_multi_kernel, dim3((unsigned)total_tiles), dim3(256), 0, as_stream(stream), src_base,
+                     (bf16_t*)dst_base, table, n_mats);
+  return check_launch("cast_transpose_bf16_multi");
 }
 
 extern "C" int dinox_gelu_fwd(const float* x, float* y, int64_t n, void* stream) {

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdinox_hip.so")
+LIB_PATH = os.environ.get("DINOX_LIB") or os.path.join(_HERE, "libdinox_hip.so")     # DINOX_LIB: A/B another build of the same ABI
 
 F32, BF16 = 0, 1
 EPI_BIAS, EPI_GELU, EPI_DGELU, EPI_RESIDUAL, EPI_ACCUM, EPI_AUXGRAD = 1, 2, 4, 8, 16, 32
@@ -60,6 +60,7 @@ SIGNATURES = {
     "dinox_sumsq": (i32, [vp, i64, vp, vp, vp]),
     "dinox_cast_bf16": (i32, [vp, vp, i64, vp]),
     "dinox_cast_transpose_bf16": (i32, [vp, vp, i32, i32, vp]),
+    "dinox_cast_transpose_bf16_multi": (i32, [vp, vp, vp, i32, i64, vp]),
     "dinox_gelu_fwd": (i32, [vp, vp, i64, vp]),
     "dinox_gelu_bwd": (i32, [vp, vp, vp, i64, vp]),
 }

@@ -93,6 +93,7 @@ class GradBucketer:
                 for j in members:
                     self.bucket_of[j] = b
                 hi = None
+        self._seen: set = set()
         self.active = True          # False on all but the last micro-batch of a gradient-accumulation group
         self._hooks = []
         if self.world > 1:
@@ -106,11 +107,15 @@ class GradBucketer:
         return hook
 
     def arm(self) -> None:
+        self._seen = set()
         for b in self.buckets:
             b.pending = b.n_params
             b.work = None
 
     def grad_ready(self, i: int) -> None:
+        if i in self._seen:         # autograd runs the post-accumulate hook even for a parameter whose gradient went straight into
+            return                  # the arena (ops._GradSink announced it already): count every parameter once per step
+        self._seen.add(i)
         b = self.buckets[self.bucket_of[i]]
         b.pending -= 1
         if b.pending == 0 and self.world > 1 and self.active:

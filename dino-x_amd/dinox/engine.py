@@ -12,7 +12,8 @@ Follows the order of the reference loop (scripts/phase5_big_run.py:1692-1802) fo
 
 What is different from the reference, by design:
   * parameters, gradients, Adam moments and teacher weights live in flat fp32 arenas, so the grad-norm,
-    AdamW and EMA are ONE kernel pass (dinox_adamw_ema) instead of 161 x (.item() + 2 EMA launches);
+    AdamW and EMA are ONE kernel pass (dinox_adamw_ema) instead of 161 x (.item() + 2 EMA launches); the dW products
+    accumulate straight into the gradient arena (ops._GradSink), which is zeroed once per optimiser step;
   * no host synchronisation inside a step: loss and grad-norm stay on the device until asked for;
   * data parallel: bucketed RCCL all-reduce of the gradient arena overlapped with backward, centre
     batch-mean all-reduced, 1/world folded into the AdamW kernel (dinox/dp.py).
@@ -52,9 +53,9 @@ class StepHyperParams:
     adam_eps: float = 1e-8
 
 
-def flatten_parameters(module: torch.nn.Module, align: int = 4) -> Tuple[torch.Tensor, List[torch.nn.Parameter], List[int]]:
-    """Move every parameter of ``module`` into one flat fp32 arena (each at a 16-byte aligned offset)
-    and re-point ``p.data`` at its slice.  Returns (arena, params in arena order, element offsets)."""
+def flatten_parameters(module: torch.nn.Module, align: int = 8) -> Tuple[torch.Tensor, List[torch.nn.Parameter], List[int]]:
+    """Move every parameter of ``module`` into one flat fp32 arena (each at an offset of a multiple of 8 elements, so that
+    both the fp32 slice and the same slice of a bf16 image of the arena are 16-byte aligned) and re-point ``p.data`` at its slice.  Returns (arena, params in arena order, element offsets)."""
     params = list(module.parameters())
     if not params:
         raise ValueError("module has no parameters")
@@ -105,6 +106,7 @@ class TrainEngine:
         # the teacher forward has no data dependence on the student forward: it runs on its own HIP stream so the two
         # kernel chains fill each other's tails (every launch ends with a partial last round of workgroups)
         self.side_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        self.shadows = [ops.ArenaShadow(self.flat_p, self.params, self.offsets), ops.ArenaShadow(self.flat_t, t_params, t_off)]
         self.step_count = 0          # micro-batches seen (drives the LR schedule, like the reference)
         self.opt_steps = 0           # optimiser steps taken (AdamW bias correction)
         self.last = {}
@@ -124,6 +126,10 @@ class TrainEngine:
             self.flat_g.zero_()
         self.bucketer.active = last
         self.bucketer.arm()
+        if ops.grad_sink.owner is not self:      # weight gradients accumulate straight into flat_g (ops._GradSink)
+            ops.grad_sink.register(self, self.params, self.bucketer.grad_ready if self.world > 1 else None)
+            ops.weight_cache.shadows = self.shadows
+        ops.grad_sink.uses.clear()
         with ops.compute_dtype(self.compute_dtype):
             main = torch.cuda.current_stream()
             # opt-in (DINOX_SIDE_STREAM=1): +1.3 % measured, but concurrent chains blur per-kernel timings, so bench/profiles keep it off
@@ -162,6 +168,9 @@ class TrainEngine:
                                  weight_decay=hp.weight_decay, beta1=hp.beta1, beta2=hp.beta2, eps=hp.adam_eps,
                                  step_t=self.opt_steps, ema=hp.ema, grad_scale=1.0 / self.world)
             ops.weight_cache.clear()     # master weights changed under the bf16 copies
+            if self.compute_dtype == torch.bfloat16:
+                for sh in self.shadows:  # one cast launch per arena (+ one for every transposed matrix backward uses)
+                    sh.refresh()
         else:
             gsq = torch.zeros(1, device=batch.device)       # the reference logs grad-norm 0 between optimiser steps
         self.step_count += 1

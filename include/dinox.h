@@ -91,7 +91,8 @@ typedef struct dinox_gemm_args {
   int64_t ldr;
   void* aux;
   int64_t ldaux;
-  float* colsum;                       /* optional, transA = 1 only: colsum[m] = sum_k A(m,k) (overwritten) -- the bias
+  float* colsum;                       /* optional, transA = 1 only: colsum[m] = sum_k A(m,k) (overwritten; added to
+                                        * under ACCUM, like C) -- the bias
                                         * gradient sum_rows(dY) rides along the dW = dY^T X product that already streams dY */
 } dinox_gemm_args;
 
@@ -209,6 +210,10 @@ int dinox_adamw_ema(float* p, const float* g, float* m, float* v, float* teacher
 int dinox_sumsq(const float* x, int64_t n, float* out, float* ws, void* stream);
 int dinox_cast_bf16(const float* src, void* dst, int64_t n, void* stream);
 int dinox_cast_transpose_bf16(const float* src, void* dst, int R, int C, void* stream);
+/* All matrices of a parameter arena in one launch: table (device, int64 [n_mats][4]) holds per matrix {element offset (the same
+ * in src_base and dst_base), R, C, index of its first 32x32 tile}; total_tiles = sum of ceil(R/32)*ceil(C/32). */
+int dinox_cast_transpose_bf16_multi(const float* src_base, void* dst_base, const int64_t* table, int n_mats,
+                                    int64_t total_tiles, void* stream);
 /* Elementwise helpers used by the host-side modules: y = gelu_erf(x) / dx = dy * gelu_erf'(x) (fp32). */
 int dinox_gelu_fwd(const float* x, float* y, int64_t n, void* stream);
 int dinox_gelu_bwd(const float* dy, const float* x, float* dx, int64_t n, void* stream);

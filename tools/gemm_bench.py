@@ -26,10 +26,10 @@ res = rf(M, D)
 pre = torch.empty(M, H, dtype=torch.bfloat16, device=dev)
 case("qkv   NT K384 N1152 bias        ", lambda: ops.gemm(x, wqkv, bias=bq), 2 * M * D * 3 * D, M * D * 2 + M * 3 * D * 2)
 case("proj  NT K384 N384  bias+res f32", lambda: ops.gemm(x, wproj, bias=bd, residual=res, out_dtype=torch.float32), 2 * M * D * D, M * D * 2 + 2 * M * D * 4)
-case("fc1   NT K384 N1536 bias+gelu+aux", lambda: ops.gemm(x, w1, bias=bh, gelu=True, aux=pre), 2 * M * D * H, M * D * 2 + 2 * M * H * 2)
+case("fc1   NT K384 N1536 bias+gelu+aux", lambda: ops.gemm(x, w1, bias=bh, gelu=True, aux=pre, auxgrad=True), 2 * M * D * H, M * D * 2 + 2 * M * H * 2)
 case("fc1t  NT K384 N1536 bias+gelu    ", lambda: ops.gemm(x, w1, bias=bh, gelu=True), 2 * M * D * H, M * D * 2 + M * H * 2)
 case("fc2   NT K1536 N384 bias+res f32", lambda: ops.gemm(xh, w2, bias=bd, residual=res, out_dtype=torch.float32), 2 * M * D * H, M * H * 2 + 2 * M * D * 4)
-case("dact  NT K384 N1536 dgelu        ", lambda: ops.gemm(x, w2T, dgelu=True, aux=pre), 2 * M * D * H, M * D * 2 + 2 * M * H * 2)
+case("dact  NT K384 N1536 dgelu        ", lambda: ops.gemm(x, w2T, dgelu=True, aux=pre, auxgrad=True), 2 * M * D * H, M * D * 2 + 2 * M * H * 2)
 case("dxn2  NT K1536 N384 plain        ", lambda: ops.gemm(xh, w1T), 2 * M * D * H, M * H * 2 + M * D * 2)
 case("dxn1  NT K1152 N384 plain        ", lambda: ops.gemm(x3, wqkvT), 2 * M * D * 3 * D, M * 3 * D * 2 + M * D * 2)
 db = torch.empty(H, device=dev)

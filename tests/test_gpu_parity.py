@@ -664,3 +664,67 @@ def test_gradient_accumulation_semantics(dx):
     d = (e2.flat_p - e1.flat_p).abs()
     assert float((d <= 1e-6 + 1e-4 * e1.flat_p.abs()).double().mean()) > 0.995 and float(d.max()) <= 1.1e-3
     assert float((e2.flat_t - e1.flat_t).abs().max()) <= 1.2e-4
+
+
+def test_arena_shadow_and_multi_transpose(dx):
+    """ops.ArenaShadow: one cast launch images a whole parameter arena, one launch transposes every requested matrix; both must
+    equal the per-weight casts bit for bit, and a parameter modified after the refresh must not be served."""
+    ops, arch = dx
+    from dinox.engine import flatten_parameters
+    torch.manual_seed(3)
+    mod = torch.nn.ModuleList([torch.nn.Linear(40, 72), torch.nn.Linear(72, 33, bias=False), torch.nn.Conv2d(3, 24, 5)]).to(DEV)
+    flat, params, offs = flatten_parameters(mod)
+    assert all(o % 8 == 0 for o in offs)
+    sh = ops.ArenaShadow(flat, params, offs)
+    mats = [p for p in params if p.dim() >= 2]
+    for w in mats:
+        assert sh.get(w, True) is None and sh.get(w, False) is None      # nothing imaged yet; transposes are now on the wanted list
+    sh.refresh()
+    for w in mats:
+        w2 = w.detach().reshape(w.shape[0], -1)
+        assert torch.equal(sh.get(w, False), w2.bfloat16())
+        assert torch.equal(sh.get(w, True), w2.t().contiguous().bfloat16())
+        assert sh.get(w, False).data_ptr() % 16 == 0 and sh.get(w, True).data_ptr() % 16 == 0
+    with torch.no_grad():
+        mats[0].mul_(2.0)                                                # version bump: the image is stale
+    assert sh.get(mats[0], False) is None and sh.get(mats[1], False) is not None
+    sh.refresh()
+    assert torch.equal(sh.get(mats[0], False), mats[0].detach().bfloat16())
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_grad_sink_accumulates_in_place(dx, mode):
+    """ops._GradSink: with a registered arena the dW product (and its bias column sums) lands in p.grad directly and autograd gets
+    None; the result must equal the autograd-accumulated gradient, including accumulation over two backward passes."""
+    ops, arch = dx
+    from dinox.engine import flatten_parameters
+    dt = torch.float32 if mode == "fp32" else torch.bfloat16
+    torch.manual_seed(5)
+    lin = arch.Linear(64, 136).to(DEV)
+    x = torch.randn(300, 64, device=DEV)
+
+    def run(sink):
+        for p in lin.parameters():
+            p.grad = None
+        flat, params, offs = flatten_parameters(lin)
+        g = torch.zeros_like(flat)
+        for p, o in zip(params, offs):
+            p.grad = g[o:o + p.numel()].view(p.shape)
+        events = []
+        if sink:
+            ops.grad_sink.register("test", params, events.append)
+        else:
+            ops.grad_sink.clear()
+        try:
+            with ops.compute_dtype(dt):
+                for _ in range(2):
+                    ops.grad_sink.uses.clear()
+                    lin(x).float().square().sum().backward()
+        finally:
+            ops.grad_sink.clear()
+        return g.clone(), events
+
+    ref, _ = run(False)
+    got, events = run(True)
+    assert sorted(events) == [0, 0, 1, 1]                                # weight and bias announced once per backward
+    assert rel_l2(got, ref) < (1e-6 if mode == "fp32" else 1e-5)

@@ -7,6 +7,7 @@ Follows the order of the reference loop (scripts/phase5_big_run.py:1692-1802) fo
     student fwd, teacher fwd (no grad), heads on CLS                :1741-1747
     DINO loss with the PRE-update centre, then centre EMA           :1749-1755 -> :692-720
     + gram_weight * Gram anchoring loss                             :1758-1761
+    + koleo_weight * KoLeo regulariser on the student head output   :1764-1766
     backward                                                        :1772
     global grad-norm, AdamW (wd on every parameter), EMA teacher    :1781-1802
 
@@ -48,6 +49,7 @@ class StepHyperParams:
     student_temp: float = 0.1
     center_momentum: float = 0.9
     gram_weight: float = 1.0
+    koleo_weight: float = 0.0
     beta1: float = 0.9
     beta2: float = 0.999
     adam_eps: float = 1e-8
@@ -160,6 +162,11 @@ class TrainEngine:
             else:
                 l_gram = torch.zeros((), device=batch.device)
                 loss = l_dino
+            if hp.koleo_weight > 0.0:                        # :1764-1766; nearest neighbours over the global batch under DP
+                l_koleo = ops.koleo_loss(s_out, group=self.group)
+                loss = loss + hp.koleo_weight * l_koleo
+            else:
+                l_koleo = torch.zeros((), device=batch.device)
             (loss if self.accum == 1 else loss / self.accum).backward()
         self.bucketer.finish()
         if last:
@@ -174,12 +181,13 @@ class TrainEngine:
         else:
             gsq = torch.zeros(1, device=batch.device)       # the reference logs grad-norm 0 between optimiser steps
         self.step_count += 1
-        self.last = {"loss": loss.detach(), "dino": l_dino.detach(), "gram": l_gram.detach(), "grad_norm_sq": gsq, "lr": lr}
+        self.last = {"loss": loss.detach(), "dino": l_dino.detach(), "gram": l_gram.detach(), "koleo": l_koleo.detach(),
+                     "grad_norm_sq": gsq, "lr": lr}
         return self.last
 
     # -- convenience ------------------------------------------------------------------------------
     def scalars(self) -> dict:
         """Host copies of the last step's scalars (this is the only place that synchronises)."""
         r = self.last
-        return {"loss": float(r["loss"]), "dino": float(r["dino"]), "gram": float(r["gram"]),
+        return {"loss": float(r["loss"]), "dino": float(r["dino"]), "gram": float(r["gram"]), "koleo": float(r["koleo"]),
                 "grad_norm": float(r["grad_norm_sq"]) ** 0.5, "lr": r["lr"]}

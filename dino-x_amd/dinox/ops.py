@@ -842,6 +842,65 @@ class GramLossFn(torch.autograd.Function):
         return d * g, None
 
 
+class KoLeoFn(torch.autograd.Function):
+    """KoLeo regulariser on the student head output (reference scripts/phase5_big_run.py:742-773, applied at :1764-1766):
+    -mean_i log(min_{j != i} ||x^_i - x^_j|| + eps) with x^ = F.normalize(x).  fp32 in both modes, like cdist under autocast.
+
+    Data parallel (``group`` with more than one rank): the neighbour of a row is searched over the GLOBAL batch, as the
+    single-process reference would at that batch size.  Two all-gathers (unit rows; then index + distance per row) and no
+    gradient collective: a row's gradient needs its own pair and the pairs that chose it, all of which are gathered data.
+    The value returned is this rank's mean over its own rows, so the mean over ranks is the global loss."""
+
+    @staticmethod
+    def forward(ctx, x, eps, group):
+        import torch.distributed as dist
+        _need_cuda(x)
+        x = _c(x.float())
+        V, D = x.shape
+        dev = x.device
+        world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        rank = dist.get_rank(group) if world > 1 else 0
+        f = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
+        xh, norm, sq = f(V, D), f(V), f(V)
+        check(lib.dinox_koleo_normalize(_p(x), _p(xh), _p(norm), _p(sq), V, D, 1e-12, _stream()), "dinox_koleo_normalize")
+        if world > 1:
+            xh_all, sq_all = f(world * V, D), f(world * V)
+            dist.all_gather_into_tensor(xh_all, xh, group=group)
+            dist.all_gather_into_tensor(sq_all, sq, group=group)
+        else:
+            xh_all, sq_all = xh, sq
+        Vg, row0 = world * V, rank * V
+        G = gemm(xh, xh_all, out_dtype=torch.float32)                       # [V, Vg] inner products, exact-fp32 MFMA
+        idx = torch.empty(V, dtype=torch.int32, device=dev)
+        dmin = f(V)
+        check(lib.dinox_koleo_nn(_p(G), Vg, _p(sq_all), _p(xh_all), row0, V, Vg, D, _p(idx), _p(dmin), _stream()), "dinox_koleo_nn")
+        if world > 1:
+            idx_all = torch.empty(Vg, dtype=torch.int32, device=dev)
+            d_all = f(Vg)
+            dist.all_gather_into_tensor(idx_all, idx, group=group)
+            dist.all_gather_into_tensor(d_all, dmin, group=group)
+        else:
+            idx_all, d_all = idx, dmin
+        ctx.save_for_backward(xh_all, idx_all, d_all, norm)
+        ctx.dims, ctx.eps = (row0, V, Vg, D), eps
+        return -torch.log(dmin + eps).mean()
+
+    @staticmethod
+    def backward(ctx, g):
+        xh_all, idx_all, d_all, norm = ctx.saved_tensors
+        row0, V, Vg, D = ctx.dims
+        dx = torch.empty((V, D), dtype=torch.float32, device=xh_all.device)
+        # the kernel takes the upstream gradient as a host scalar folded into gscale; keep it on the device instead: run with
+        # gscale = 1/V and scale the result by g (one small elementwise multiply, no host sync)
+        check(lib.dinox_koleo_bwd(_p(xh_all), _p(idx_all), _p(d_all), _p(norm), row0, V, Vg, D, 1.0 / V, ctx.eps, 1e-12, _p(dx), _stream()),
+              "dinox_koleo_bwd")
+        return dx * g, None, None
+
+
+def koleo_loss(x: Tensor, eps: float = 1e-8, group=None) -> Tensor:
+    return KoLeoFn.apply(x, eps, group)
+
+
 def adamw_ema_(p: Tensor, g: Tensor, m: Tensor, v: Tensor, teacher: Optional[Tensor], *, lr: float, weight_decay: float,
                beta1: float, beta2: float, eps: float, step_t: int, ema: float, grad_scale: float = 1.0) -> Tensor:
     """Fused grad-norm + AdamW + EMA over flat fp32 arenas; returns gnorm_sq[1] (device)."""

@@ -15,8 +15,9 @@ loop :1686-1997), and the same importable names other reference scripts/tests us
 * one process per GPU under ``torch.distributed.run`` gives data parallelism (each rank its own data shard);
 * the input pipeline is torchvision-free (PIL + torch CPU ops) and there is an explicit ``--synthetic N`` source of
   seeded 16-bit HU slice stacks for runs without a dataset (this environment has none);
-* not wired to the engine yet (exit with a message): ``--loss-type simclr|mae``, ``--koleo-weight > 0``,
-  ``--device cpu`` (there is no CPU compute path).
+* ``--koleo-weight`` searches nearest neighbours over the GLOBAL batch under data parallelism (dinox.ops.KoLeoFn);
+* not wired to the engine yet (exit with a message): ``--loss-type simclr|mae``, ``--device cpu`` (there is no CPU
+  compute path).
 """
 from __future__ import annotations
 
@@ -574,8 +575,6 @@ def main(argv=None) -> None:
     args = build_parser().parse_args(argv)
     if args.loss_type != "dino":
         raise SystemExit(f"--loss-type {args.loss_type} is not wired to the MI355X engine yet (only 'dino'; see DESIGN.md section 7)")
-    if args.koleo_weight > 0.0:
-        raise SystemExit("--koleo-weight > 0 is not wired to the MI355X engine yet (see DESIGN.md section 7)")
     if args.amp and args.amp_dtype != "bfloat16":
         raise SystemExit("the HIP path supports --amp-dtype bfloat16 only")
     rank, world, local = init_process_group()
@@ -696,7 +695,8 @@ def main(argv=None) -> None:
     teacher.load_state_dict(student.state_dict())
     hp = StepHyperParams(lr=args.lr, min_lr=args.min_lr, warmup_steps=args.warmup_steps, max_steps=args.max_steps,
                          weight_decay=args.weight_decay, ema=args.ema, teacher_temp=args.teacher_temp, student_temp=args.student_temp,
-                         center_momentum=args.center_momentum, gram_weight=args.gram_weight)
+                         center_momentum=args.center_momentum, gram_weight=args.gram_weight,
+                         koleo_weight=args.koleo_weight)
     eng = TrainEngine(student, teacher, model_cfg.out_dim, hp, amp_dtype=torch.bfloat16 if args.amp else None,
                       accumulation_steps=args.accumulation_steps)
     start_step = 0

@@ -196,6 +196,26 @@ int dinox_gram_normalize_bwd(const float* dxh, const void* shat, const float* sn
                              float* dfeats, int V, int N, int D, int shat_dtype, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * KoLeo regulariser -- replaces KoLeoLoss.forward (scripts/phase5_big_run.py:742-773), which the loop applies
+ * to the student head output (:1764-1766): x^ = F.normalize(x); d_i = min_{j != i} ||x^_i - x^_j||;
+ * loss = -mean_i log(d_i + eps).  fp32 throughout.  The all-pairs products G = X^_local X^_all^T go through
+ * dinox_gemm (fp32); these entries are the pieces around it.  "local" rows are this rank's V_l rows, at
+ * global positions row0 .. row0+V_l-1 of the V_g gathered rows (V_l = V_g, row0 = 0 on one GPU).
+ *   normalize: xh = x / max(||x||, eps); norm[r] = ||x_r||; sq[r] = ||xh_r||^2.
+ *   nn:        idx[i] = argmin_{j != row0+i} (sq_i + sq_j - 2 G[i][j]) (lowest j on ties; -1 if V_g = 1),
+ *              dist[i] = ||xh_i - xh_idx|| measured on the rows themselves.
+ *   bwd:       dx[r] = d(-gscale * sum_i log(dist_i + eps)) / dx_r over ALL V_g pairs (idx_all/dist_all are
+ *              the gathered results of nn): the row's own pair plus every pair that chose r as neighbour,
+ *              then back through the normalisation (norm_eps = the eps given to normalize).
+ *              gscale = upstream gradient / V_l.  V_g <= 15359.
+ * ------------------------------------------------------------------------------------------ */
+int dinox_koleo_normalize(const float* x, float* xh, float* norm, float* sq, int64_t V, int D, float eps, void* stream);
+int dinox_koleo_nn(const float* G, int64_t ldg, const float* sq_all, const float* xh_all, int row0, int V_l, int V_g, int D,
+                   int* idx, float* dist, void* stream);
+int dinox_koleo_bwd(const float* xh_all, const int* idx_all, const float* dist_all, const float* norm_loc, int row0, int V_l,
+                    int V_g, int D, float gscale, float eps, float norm_eps, float* dx, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Optimiser tail -- replaces the per-parameter grad-norm loop (scripts/phase5_big_run.py:1784-1789),
  * torch.optim.AdamW.step (:1794; betas .9/.999, eps 1e-8, decoupled decay on EVERY parameter) and the
  * per-parameter EMA teacher update (:1799-1802) with ONE pass over flat fp32 arenas of n elements.

@@ -1,5 +1,5 @@
-"""Worker of test_engine_data_parallel_two_ranks_match_single_process: one TrainEngine step (fp32 parity mode) on this
-rank's shard of a fixed global batch.  Run with RANK/WORLD_SIZE/MASTER_* set (WORLD_SIZE=1: whole batch)."""
+"""Worker of test_engine_data_parallel_two_ranks_match_single_process: two TrainEngine steps (fp32 parity mode, DINO + Gram +
+KoLeo, whose nearest neighbours span the global batch) on this rank's shard of a fixed global batch.  Run with RANK/WORLD_SIZE/MASTER_* set (WORLD_SIZE=1: whole batch)."""
 import os
 import sys
 
@@ -24,7 +24,7 @@ student = arch.DinoStudentTeacher(arch.PatchViT(**kw), 256)
 torch.nn.init.xavier_uniform_(student.backbone.scale_embed.mlp[2].weight)
 teacher = arch.DinoStudentTeacher(arch.PatchViT(**kw), 256)
 teacher.load_state_dict(student.state_dict())
-eng = TrainEngine(student.to(dev), teacher.to(dev), 256, StepHyperParams(lr=1e-3, warmup_steps=1, max_steps=10, ema=0.99),
+eng = TrainEngine(student.to(dev), teacher.to(dev), 256, StepHyperParams(lr=1e-3, warmup_steps=1, max_steps=10, ema=0.99, koleo_weight=0.1),
                   bucket_bytes=64 << 10)
 assert world == 1 or len(eng.bucketer.buckets) >= 3
 g = torch.Generator().manual_seed(7)

@@ -16,6 +16,7 @@ Fixtures
   ops_scale_embed.npz reference ScaleEmbedding     fwd + grads (non-zero output projection)
   dino_loss.npz       DINOLoss (2 calls, centre carried), grad wrt student logits
   gram_loss.npz       compute_gram_anchoring_loss, grad wrt student feats
+  koleo_loss.npz      KoLeoLoss (10 rows: cdist direct path; 40 rows: cdist matmul path), grad wrt input
   vit_tiny.npz        DinoStudentTeacher(PatchViT 56/14/64/2/2 regs4 scale-aware) fwd taps,
                       DINO+Gram loss, every parameter gradient
   vit_plain.npz       PatchViT 28/14/32/1/2 no registers, not scale-aware: fwd only
@@ -149,6 +150,21 @@ def gram_loss():
     l = P.compute_gram_anchoring_loss(sf, tf)
     l.backward()
     save("gram_loss.npz", sf=sf, tf=tf, loss=l, dsf=sf.grad, gram_s=P.compute_gram_matrix(sf.detach()[:, 1:]))
+
+
+def koleo_loss():
+    """KoLeoLoss (phase5_big_run.py:742-773) on the student head output: a 10-row case (torch.cdist's direct path) and a
+    40-row case (> 25 rows: its matmul path), each with the gradient wrt the input."""
+    g = torch.Generator().manual_seed(23)
+    out = {}
+    for tag, (V, K) in {"small": (10, 48), "mm": (40, 256)}.items():
+        x = (2.0 * torch.randn(V, K, generator=g)).requires_grad_(True)
+        with torch.no_grad():
+            x[3] = x[7] + 0.05 * torch.randn(K, generator=g)      # a close pair: both rows pick each other
+        l = P.KoLeoLoss()(x)
+        l.backward()
+        out.update({f"{tag}_x": x, f"{tag}_loss": l, f"{tag}_dx": x.grad})
+    save("koleo_loss.npz", **out)
 
 
 def vit_tiny():
@@ -300,6 +316,7 @@ if __name__ == "__main__":
     ops_scale_embed()
     dino_loss()
     gram_loss()
+    koleo_loss()
     vit_tiny()
     vit_plain()
     step_tiny()

@@ -514,7 +514,8 @@ def test_cli_train_checkpoint_resume(dx, tmp_path, capsys):
     cli = _cli()
     common = ["--config", "vit-tiny", "--vit-patch", "16", "--vit-dim", "64", "--vit-depth", "2", "--vit-heads", "2", "--out-dim", "256",
               "--img-size", "32", "--batch-size", "8", "--scale-aware", "--amp", "--synthetic", "32", "--num-workers", "0",
-              "--warmup-steps", "2", "--lr", "1e-3", "--ckpt-every", "3", "--run-dir", str(tmp_path / "runs")]
+              "--warmup-steps", "2", "--lr", "1e-3", "--ckpt-every", "3", "--koleo-weight", "0.1", "--grad-checkpoint",
+              "--run-dir", str(tmp_path / "runs")]
     log1 = tmp_path / "a.jsonl"
     cli.main(common + ["--max-steps", "6", "--log-json", str(log1), "--run-suffix", "a"])
     out = capsys.readouterr().out
@@ -728,3 +729,99 @@ def test_grad_sink_accumulates_in_place(dx, mode):
     got, events = run(True)
     assert sorted(events) == [0, 0, 1, 1]                                # weight and bias announced once per backward
     assert rel_l2(got, ref) < (1e-6 if mode == "fp32" else 1e-5)
+
+
+@pytest.mark.parametrize("tag", ["small", "mm"])
+def test_koleo_loss_golden(dx, tag):
+    """ops.koleo_loss vs the reference KoLeoLoss fixture (phase5_big_run.py:742-773): loss and input gradient.  Tolerances as
+    in tests/test_oracle_golden.py: the 40-row fixture went through cdist's matmul route, which loses digits on its close pair."""
+    ops, _ = dx
+    g = load_golden("koleo_loss.npz")
+    x = t(g[f"{tag}_x"]).to(DEV).requires_grad_(True)
+    l = ops.koleo_loss(x)
+    l.backward()
+    assert float(l) == pytest.approx(float(g[f"{tag}_loss"]), rel=1e-5 if tag == "small" else 5e-4, abs=1e-6)
+    assert rel_l2(x.grad, g[f"{tag}_dx"]) < (2e-5 if tag == "small" else 1e-3)
+
+
+def test_koleo_loss_vs_oracle_and_edges(dx):
+    """Head-sized rows (512 x 8192) against the oracle; then the edge cases: an exact duplicate pair (distance 0: loss term
+    -log(eps), no gradient through that pair, as cdist's backward gives), an all-zero row (F.normalize's eps clamp), two rows."""
+    ops, _ = dx
+    from oracle import dinox_oracle as O
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(96, 8192, generator=g)
+    xo = x.clone().requires_grad_(True)
+    lo = O.koleo_loss(xo)
+    lo.backward()
+    xg = x.to(DEV).requires_grad_(True)
+    lg = ops.koleo_loss(xg)
+    (3.0 * lg).backward()
+    assert float(lg) == pytest.approx(float(lo), rel=1e-5)
+    assert rel_l2(xg.grad, 3.0 * xo.grad) < 1e-4
+    # duplicate pair + zero row
+    y = torch.randn(12, 64, generator=g)
+    y[5] = y[2]
+    y[9] = 0.0
+    yg = y.to(DEV).requires_grad_(True)
+    l = ops.koleo_loss(yg)
+    l.backward()
+    assert float(l) == pytest.approx(float(O.koleo_loss(y)), rel=1e-5)            # includes two -log(1e-8) terms
+    assert torch.isfinite(yg.grad).all()
+    # rows 2 and 5 only receive gradient as someone else's neighbour, never through their own zero distance
+    y2 = torch.randn(2, 16, generator=g)
+    y2g = y2.to(DEV).requires_grad_(True)
+    l2 = ops.koleo_loss(y2g)
+    l2.backward()
+    y2o = y2.clone().requires_grad_(True)
+    O.koleo_loss(y2o).backward()
+    assert float(l2) == pytest.approx(float(O.koleo_loss(y2)), rel=1e-6) and rel_l2(y2g.grad, y2o.grad) < 1e-5
+
+
+def test_step_with_koleo_matches_oracle(dx):
+    """One engine step with --koleo-weight 0.1 (the value of every production run, docs/EXPERIMENTS.md) against the oracle's
+    train_step on the tiny scale-aware model."""
+    ops, arch = dx
+    from dinox.engine import StepHyperParams, TrainEngine
+    from oracle import dinox_oracle as O
+    cfg = O.VitCfg(img_size=56, patch=14, dim=64, depth=2, heads=2, num_registers=4, scale_aware=True, out_dim=128)
+    st = O.init_state(cfg, O.random_params(cfg, seed=4))
+    g = torch.Generator().manual_seed(6)
+    batch = torch.randn(12, 3, 56, 56, generator=g)
+    sp2 = torch.rand(12, 3, generator=g) + 0.5
+    hp_o = O.HyperParams(lr=1e-3, warmup_steps=1, max_steps=10, ema=0.99, koleo_weight=0.1)
+    sd = {k: v.clone() for k, v in st.student.items()}
+    want = O.train_step(st, batch, sp2, hp_o)
+    kw = dict(img_size=56, patch=14, dim=64, depth=2, heads=2, num_registers=4, scale_aware=True)
+    student = arch.DinoStudentTeacher(arch.PatchViT(**kw), 128)
+    teacher = arch.DinoStudentTeacher(arch.PatchViT(**kw), 128)
+    student.load_state_dict(sd)
+    teacher.load_state_dict(sd)
+    eng = TrainEngine(student.to(DEV), teacher.to(DEV), 128, StepHyperParams(lr=1e-3, warmup_steps=1, max_steps=10, ema=0.99, koleo_weight=0.1))
+    eng.step(batch.to(DEV), sp2.to(DEV))
+    got = eng.scalars()
+    assert got["koleo"] != 0.0
+    for k in ("loss", "grad_norm"):
+        assert got[k] == pytest.approx(want[k], rel=1e-3), (k, got[k], want[k])
+    names = [n for n, _ in student.named_parameters()]
+    for n, p in zip(names, eng.params):
+        ref = want["grads"][n]
+        if float(ref.abs().max()) > 1e-6:
+            assert rel_l2(p.grad, ref) < 2e-3, n
+
+
+def test_grad_checkpoint_matches_plain(dx):
+    """--grad-checkpoint (zoo/arch.py:232-233): recomputing every block in backward must give the gradients of the plain run."""
+    ops, arch = dx
+    kw = dict(img_size=56, patch=14, dim=64, depth=3, heads=2, num_registers=4, scale_aware=True)
+    g = torch.Generator().manual_seed(8)
+    x, sp = torch.randn(4, 3, 56, 56, generator=g).to(DEV), (torch.rand(4, 3, generator=g) + 0.5).to(DEV)
+    grads = []
+    for ck in (False, True):
+        torch.manual_seed(12)
+        m = arch.PatchViT(use_grad_checkpoint=ck, **kw).to(DEV).train()
+        m(x, spacing=sp).square().mean().backward()
+        grads.append({n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
+    assert grads[0].keys() == grads[1].keys()
+    for n in grads[0]:
+        assert torch.allclose(grads[0][n], grads[1][n], rtol=1e-5, atol=1e-8), n

@@ -218,3 +218,18 @@ def test_survey_known_answer_model():
     out.pow(2).mean().backward()
     assert float(p["backbone.blocks.0.attn.qkv.weight"].grad.abs().mean()) == pytest.approx(6.03e-08, rel=2e-2)
     assert float(p["backbone.scale_embed.mlp.0.weight"].grad.abs().mean()) == pytest.approx(1.24058e-05, rel=1e-3)
+
+
+@pytest.mark.parametrize("tag", ["small", "mm"])
+def test_koleo_loss_golden(golden, tag):
+    """oracle.koleo_loss vs the reference KoLeoLoss (phase5_big_run.py:742-773): loss and input gradient, on torch.cdist's
+    direct route (10 rows) and its matmul route (40 rows)."""
+    g = golden("koleo_loss.npz")
+    x = t(g[f"{tag}_x"]).requires_grad_(True)
+    l = O.koleo_loss(x)
+    l.backward()
+    # the 40-row case holds a close pair (d ~ 0.03): cdist's matmul route (|a|^2+|b|^2-2ab) loses ~3 digits of that distance to
+    # cancellation, the direct distance here does not; 5e-4 covers it (the path's fp32 gate is 1e-3)
+    assert float(l) == pytest.approx(float(g[f"{tag}_loss"]), rel=1e-5 if tag == "small" else 5e-4, abs=1e-6)
+    ref = t(g[f"{tag}_dx"])
+    assert float((x.grad - ref).norm() / ref.norm()) < (2e-5 if tag == "small" else 1e-3)

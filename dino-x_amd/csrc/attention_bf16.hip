@@ -12,9 +12,15 @@
 // of the next product (P^T)^T . V  /  (dS^T)^T . K  with no lane movement (guide section 3, "An accumulator
 // tile as the next MFMA's operand"); the other operand is fetched in the matching permuted k order.
 //
-//   fwd   : one wave per 32 queries.   S^T (all key tiles, registers) -> softmax -> O = P V ; writes lse.
-//   bwd dQ: one wave per 32 queries.   streams key tiles: S^T, dP^T = V . dO^T, dS^T -> dQ += dS K.
-//   bwd dKV: one wave per 32 keys.     streams query tiles: S = Q . K^T, dP = dO . V^T -> dV += P^T dO, dK += dS^T Q.
+//   fwd   : attn_fwd_bf16_persist: persistent workgroups, one (image, head) per iteration, the NEXT head's K,V image
+//           streamed into the second LDS buffer by LDS-DMA (buffer_load ... lds, swizzle on the source address) while this
+//           one computes; one wave per 32 queries.  Up to 7 key tiles (N <= 224): S^T of the whole strip stays in
+//           registers (one pass: max, exp, sum, O = P V); more keys: two passes over the key tiles.  Writes lse.
+//           attn_fwd_bf16<NKT> is the non-persistent two-pass form (DINOX_ATTN_NO_PERSIST=1, A/B only).
+//   bwd dQ: one wave per 32 queries.   K,V images by LDS-DMA; streams key tiles: S^T, dP^T = V . dO^T, dS^T -> dQ += dS K;
+//           writes delta = rowsum(dO o O) to the workspace for the dKV kernel.
+//   bwd dKV: one wave per 32 keys.     Q,dO images by LDS-DMA, lse/delta in LDS; streams query tiles: S = Q . K^T,
+//           dP = dO . V^T -> dV += P^T dO, dK += dS^T Q.
 // (two backward kernels recompute S/dP once more than a single fused pass would: 7 instead of 5 tile
 //  products, traded for no cross-wave reduction of dQ; attention is ~8 % of the block's FLOPs.)
 #include <cstdlib>

@@ -56,6 +56,8 @@ SIGNATURES = {
     "dinox_gram_normalize": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "dinox_sqsum": (i32, [vp, i64, f32, vp, vp, vp]),
     "dinox_gram_normalize_bwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "dinox_slice_views_lds_bytes": (i64, [i32, i32]),
+    "dinox_slice_views": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
     "dinox_koleo_normalize": (i32, [vp, vp, vp, vp, i64, i32, f32, vp]),
     "dinox_koleo_nn": (i32, [vp, i64, vp, vp, i32, i32, i32, i32, vp, vp, vp]),
     "dinox_koleo_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, f32, vp, vp]),

@@ -14,7 +14,8 @@ loop :1686-1997), and the same importable names other reference scripts/tests us
   ``state_dict`` format so reference checkpoints resume here and vice versa;
 * one process per GPU under ``torch.distributed.run`` gives data parallelism (each rank its own data shard);
 * the input pipeline is torchvision-free (PIL + torch CPU ops) and there is an explicit ``--synthetic N`` source of
-  seeded 16-bit HU slice stacks for runs without a dataset (this environment has none);
+  seeded 16-bit HU slice stacks for runs without a dataset (this environment has none); ``--gpu-views`` moves everything
+  after the PNG decode (window, antialiased bicubic RandomResizedCrop, flip, normalise) into one HIP kernel (dinox/views.py);
 * ``--koleo-weight`` searches nearest neighbours over the GLOBAL batch under data parallelism (dinox.ops.KoLeoFn);
 * not wired to the engine yet (exit with a message): ``--loss-type simclr|mae``, ``--device cpu`` (there is no CPU
   compute path).
@@ -211,25 +212,11 @@ _STD = torch.tensor([0.229, 0.224, 0.225]).view(3, 1, 1)
 
 def random_resized_crop_flip_normalize(x: torch.Tensor, size: int, scale=(0.3, 1.0), ratio=(3.0 / 4.0, 4.0 / 3.0)) -> torch.Tensor:
     """(3,H,W) in [0,1] -> (3,size,size): RandomResizedCrop (bicubic) + horizontal flip (p=.5) + ImageNet normalise,
-    the augmentation of the reference pipeline (scripts/phase5_big_run.py:493-497), drawn from Python's ``random``."""
+    the augmentation of the reference pipeline (scripts/phase5_big_run.py:493-497), drawn from Python's ``random``
+    (dinox.views.draw_crop_box: the same draws feed the device-side pipeline of ``--gpu-views``)."""
+    from dinox.views import draw_crop_box
     _, H, W = x.shape
-    area = H * W
-    top = left = 0
-    h, w = H, W
-    for _ in range(10):
-        target = area * random.uniform(scale[0], scale[1])
-        ar = math.exp(random.uniform(math.log(ratio[0]), math.log(ratio[1])))
-        cw, ch = int(round(math.sqrt(target * ar))), int(round(math.sqrt(target / ar)))
-        if 0 < cw <= W and 0 < ch <= H:
-            top, left, h, w = random.randint(0, H - ch), random.randint(0, W - cw), ch, cw
-            break
-    else:                                                   # central crop at the clamped aspect ratio
-        in_ratio = W / H
-        if in_ratio < ratio[0]:
-            w, h = W, int(round(W / ratio[0]))
-        elif in_ratio > ratio[1]:
-            h, w = H, int(round(H * ratio[1]))
-        top, left = (H - h) // 2, (W - w) // 2
+    top, left, h, w = draw_crop_box(H, W, scale, ratio)
     crop = x[:, top:top + h, left:left + w].unsqueeze(0)
     out = F.interpolate(crop, size=(size, size), mode="bicubic", align_corners=False, antialias=True)[0]
     if random.random() < 0.5:
@@ -251,6 +238,7 @@ class PngDataset(torch.utils.data.Dataset):
         self.rows, self.img_size, self.scale_aware = rows, img_size, scale_aware
         self.rw_level_min, self.rw_level_max, self.rw_width_min, self.rw_width_max = rw_level_min, rw_level_max, rw_width_min, rw_width_max
         self.crop_scale = (crop_scale_min, crop_scale_max)
+        self.raw_views = False          # True: __getitem__ returns (u16 stack, view draws, spacing) for the device-side pipeline
         self._series_map: dict = {}
         for r in rows:
             self._series_map.setdefault(r.series_dir, {})[r.slice_index] = r.png_path
@@ -281,6 +269,13 @@ class PngDataset(torch.utils.data.Dataset):
                 row = self.rows[idx]
                 slices = self._stack(row)
                 spacing = torch.tensor([row.spacing_x, row.spacing_y, row.spacing_z], dtype=torch.float32)
+                if self.raw_views:      # --gpu-views: ship the u16 stack and the draws of both views; dinox_slice_views does the rest
+                    from dinox.views import draw_view
+                    stack = np.stack([np.asarray(sl, dtype=np.uint16) for sl in slices], 0)
+                    H, W = stack.shape[1:]
+                    kw = dict(rw_level=(self.rw_level_min, self.rw_level_max), rw_width=(self.rw_width_min, self.rw_width_max),
+                              crop_scale=self.crop_scale)
+                    return stack, [draw_view(H, W, **kw), draw_view(H, W, **kw)], spacing
                 return [self._view(slices), self._view(slices)], spacing
             except Exception as e:
                 print(f"⚠️  Data loading error at index {idx} ({self.rows[idx].png_path}): {e}")
@@ -548,6 +543,9 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--log-json", type=Path, default=None, help="Write one JSON line per training step to this file")
     # extension (not in the reference): data source for environments without a dataset
     ap.add_argument("--synthetic", type=int, default=0, metavar="N", help="Train on N seeded synthetic HU slice stacks instead of --index-csv")
+    ap.add_argument("--gpu-views", action="store_true",
+                    help="Build both views on the GPU (HU decode, window, antialiased bicubic RandomResizedCrop, flip, normalise in one "
+                         "kernel); DataLoader workers then only decode PNGs")
     return ap
 
 
@@ -677,8 +675,12 @@ def main(argv=None) -> None:
     def _worker_init(worker_id: int) -> None:
         _seed_all(args.train_seed + 1000 * rank + worker_id)
 
-    common = dict(num_workers=hw.num_workers, pin_memory=hw.pin_memory, worker_init_fn=_worker_init, collate_fn=dino_collate,
-                  persistent_workers=hw.num_workers > 0)
+    ds.raw_views = bool(args.gpu_views)
+    if args.gpu_views:
+        from dinox.views import collate_stacks, make_views
+        say("gpu_views=True")
+    common = dict(num_workers=hw.num_workers, pin_memory=hw.pin_memory and not args.gpu_views, worker_init_fn=_worker_init,
+                  collate_fn=collate_stacks if args.gpu_views else dino_collate, persistent_workers=hw.num_workers > 0)
     if args.diverse_batches:
         sampler = DiverseBatchSampler(rows, batch_size=args.batch_size, drop_last=True, generator=gen)
         dl = torch.utils.data.DataLoader(ds, batch_sampler=sampler, **common)
@@ -723,11 +725,16 @@ def main(argv=None) -> None:
             step -= 1
             break
         try:
-            views, spacing = next(it)
+            item = next(it)
         except StopIteration:
             it = iter(dl)
-            views, spacing = next(it)
-        batch = torch.cat(views, 0).to(device, non_blocking=True)
+            item = next(it)
+        if args.gpu_views:
+            sb = item.to(device)
+            batch, spacing = make_views(sb, args.img_size), sb.spacing
+        else:
+            views, spacing = item
+            batch = torch.cat(views, 0).to(device, non_blocking=True)
         sp2 = torch.cat([spacing, spacing], 0).to(device, non_blocking=True) if args.scale_aware else None
         out = eng.step(batch, sp2)
         cur = (step, out["loss"], out["lr"])

@@ -196,6 +196,19 @@ int dinox_gram_normalize_bwd(const float* dxh, const void* shat, const float* sn
                              float* dfeats, int V, int N, int D, int shat_dtype, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * View pipeline for the 2.5D slice stacks -- replaces, after the PNG decode, PngDataset._load_hu01 and the
+ * torchvision transform stack (scripts/phase5_big_run.py:493-497, 516-528, 549-555): stored u16 -> HU ->
+ * window -> RandomResizedCrop (antialiased bicubic = torch's _upsample_bicubic2d_aa, align_corners = 0) ->
+ * horizontal flip -> (x - mean) / std, one kernel, out = fp32 [V][3][S][S] (the batch PatchViT.forward takes).
+ * The random draws stay on the host:  view_i[v] = {element offset of the (3,H,W) u16 stack in raw, H, W, top,
+ * left, h, w, flip};  view_f[v] = {level - width/2, max(width, 1)}   (both tables in device memory).
+ * max_crop = the largest h or w in the table (sizes the LDS footprint; a view that exceeds it is written as NaN).
+ * ------------------------------------------------------------------------------------------ */
+int64_t dinox_slice_views_lds_bytes(int S, int max_crop);
+int dinox_slice_views(const void* raw_u16, const int64_t* view_i, const float* view_f, float* out, int V, int S, int max_crop,
+                      void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * KoLeo regulariser -- replaces KoLeoLoss.forward (scripts/phase5_big_run.py:742-773), which the loop applies
  * to the student head output (:1764-1766): x^ = F.normalize(x); d_i = min_{j != i} ||x^_i - x^_j||;
  * loss = -mean_i log(d_i + eps).  fp32 throughout.  The all-pairs products G = X^_local X^_all^T go through

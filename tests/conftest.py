@@ -56,3 +56,14 @@ def golden():
             cache[name] = load_golden(name)
         return cache[name]
     return get
+
+
+@pytest.fixture(scope="session")
+def cli():
+    """The drop-in training script (dino-x_amd/scripts/phase5_big_run.py) as a module."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("phase5_big_run", os.path.join(ROOT, "dino-x_amd", "scripts", "phase5_big_run.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[spec.name] = mod            # dataclasses resolve string annotations through sys.modules
+    spec.loader.exec_module(mod)
+    return mod

@@ -32,21 +32,11 @@ TRAINING_CONFIG_FIELDS = [
     "git_commit", "data_manifest_hash", "created_at"]
 
 
-@pytest.fixture(scope="module")
-def cli():
-    spec = importlib.util.spec_from_file_location("phase5_big_run", os.path.join(PKG, "scripts", "phase5_big_run.py"))
-    mod = importlib.util.module_from_spec(spec)
-    import sys
-    sys.modules[spec.name] = mod            # dataclasses resolve string annotations through sys.modules
-    spec.loader.exec_module(mod)
-    return mod
-
-
 def test_flag_surface_matches_reference(cli):
     ap = cli.build_parser()
     have = {s for a in ap._actions for s in a.option_strings if s.startswith("--")} - {"--help"}
     assert set(REFERENCE_FLAGS) <= have
-    assert have - set(REFERENCE_FLAGS) == {"--synthetic"}            # the one documented extension
+    assert have - set(REFERENCE_FLAGS) == {"--synthetic", "--gpu-views"}     # the two documented extensions
     d = vars(ap.parse_args([]))
     for k, v in REFERENCE_DEFAULTS.items():
         assert d[k] == v, k

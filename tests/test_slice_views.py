@@ -1,0 +1,142 @@
+"""View pipeline of the 2.5D slice stacks: the NumPy restatement of torch's antialiased bicubic against the torch
+kernel itself, the host-side draw/collate logic, and (gpu) dinox_slice_views against both."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import slice_views as S
+
+DEV = "cuda"
+
+
+@pytest.mark.parametrize("h,w,size", [(300, 280, 224), (512, 512, 224), (100, 130, 224), (224, 224, 224), (37, 53, 32), (700, 900, 224)])
+def test_restatement_matches_torch_kernel(h, w, size):
+    """oracle.slice_views.resize_aa_bicubic == F.interpolate(bicubic, antialias=True) (down-, up- and mixed scaling)."""
+    img = np.random.default_rng(h + w).random((3, h, w), dtype=np.float32)
+    np.testing.assert_allclose(S.resize_aa_bicubic(img, size), S.torch_resize(img, size), atol=2e-6, rtol=0)
+
+
+def test_weights_known_answers():
+    """Identity at scale 1; rows sum to 1; support widens with the down-scale factor; edges are clipped and renormalised."""
+    for x0, n, w in S.aa_bicubic_weights(224, 224):
+        assert abs(float(w.sum()) - 1) < 1e-6 and float(w.max()) == pytest.approx(1.0, abs=1e-6)
+    wd = S.aa_bicubic_weights(512, 224)
+    assert max(n for _, n, _ in wd) in (10, 11) and wd[0][0] == 0 and wd[-1][0] + wd[-1][1] == 512
+    assert all(abs(float(w.sum()) - 1) < 1e-6 for _, _, w in wd)
+
+
+def test_hu_window_matches_reference_formula():
+    u = np.array([[32768 + 400, 32768 - 10000, 65535, 0]], dtype=np.uint16)     # 40 HU, -1000 HU, 3276.7 HU, -3276.8 HU
+    np.testing.assert_allclose(S.hu_window01(u, 40.0, 400.0), [[0.5, 0.0, 1.0, 0.0]], atol=1e-6)
+    np.testing.assert_allclose(S.hu_window01(u, 40.0, 0.5), [[0.25, 0.0, 1.0, 0.0]], atol=1e-6)     # width < 1: (40 - 39.75) / max(0.5, 1) (phase5:524)
+
+
+def test_draws_match_cpu_pipeline_order(cli):
+    """dinox.views.draw_view consumes Python's ``random`` in the order of the CPU pipeline (level, width, crop tries, flip):
+    from one seed the oracle's make_view on those draws equals the CLI's CPU view."""
+    from dinox.views import draw_view
+    rng = np.random.default_rng(3)
+    stack = rng.integers(22768, 42768, size=(3, 96, 120)).astype(np.uint16)
+    ds = cli.PngDataset([], img_size=32)
+    random.seed(11)
+    cpu = ds._view([stack[0], stack[1], stack[2]]).numpy()
+    random.seed(11)
+    p = draw_view(96, 120)
+    ours = S.make_view(stack, p.level, p.width, p.top, p.left, p.h, p.w, p.flip, 32, resize=S.torch_resize)
+    np.testing.assert_allclose(ours, cpu, atol=1e-6, rtol=0)
+
+
+def test_collate_packs_ragged_stacks():
+    from dinox.views import ViewParams, collate_stacks
+    a = np.arange(3 * 4 * 5, dtype=np.uint16).reshape(3, 4, 5) + 60000            # > 32767: survives the int16 bit-cast
+    b = np.arange(3 * 2 * 3, dtype=np.uint16).reshape(3, 2, 3)
+    v = ViewParams(0.0, 1000.0, 0, 0, 2, 2, False)
+    sb = collate_stacks([(a, [v, v], torch.ones(3)), (b, [v, v], torch.zeros(3))])
+    assert sb.offsets == [0, 60] and sb.shapes == [(4, 5), (2, 3)] and sb.raw.numel() == 78 and sb.spacing.shape == (2, 3)
+    assert len(sb.views) == 2 and len(sb.views[0]) == 2
+    back = sb.raw.numpy().view(np.uint16)
+    assert np.array_equal(back[:60].reshape(3, 4, 5), a) and np.array_equal(back[60:].reshape(3, 2, 3), b)
+
+
+# ------------------------------------------------------------------------------------------------------------- GPU
+def _batch(shapes, n_views, size, seed, crop_scale=(0.3, 1.0)):
+    from dinox.views import collate_stacks, draw_view
+    rng = np.random.default_rng(seed)
+    random.seed(seed)
+    items = []
+    for (H, W) in shapes:
+        base = rng.integers(22768, 72768, size=(3, H // 4 + 1, W // 4 + 1)).astype(np.float32)
+        img = np.kron(base, np.ones((1, 4, 4), dtype=np.float32))[:, :H, :W] + rng.normal(0, 300, (3, H, W))
+        stack = np.clip(img, 0, 65535).astype(np.uint16)
+        items.append((stack, [draw_view(H, W, crop_scale=crop_scale) for _ in range(n_views)], torch.tensor([0.7, 0.7, 2.5])))
+    return items, collate_stacks(items)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shapes,size,crop_scale", [
+    ([(512, 512)] * 3, 224, (0.3, 1.0)),                       # the reference's case: 512^2 CT slices, scale 0.3-1
+    ([(96, 120), (300, 280), (64, 64), (224, 224)], 224, (0.3, 1.0)),   # ragged stacks, up- and down-scaling in one launch
+    ([(130, 70)], 32, (0.08, 1.0)),                            # tiny crops, output not a multiple of the 16-pixel tile? (32 is; 40 below)
+    ([(200, 333)], 40, (0.5, 1.0)),
+    ([(1024, 1024)], 224, (0.9, 1.0)),                         # 4.6x down-scale: 20-tap filters, 60 KB footprint
+])
+def test_slice_views_vs_oracle(shapes, size, crop_scale):
+    """dinox_slice_views against the oracle (NumPy restatement AND torch's kernel) on the same draws: fp32, 1e-5."""
+    from dinox.views import make_views
+    items, sb = _batch(shapes, 2, size, seed=len(shapes) * 7 + size, crop_scale=crop_scale)
+    out = make_views(sb.to(DEV), size).cpu().numpy()
+    B = len(items)
+    assert out.shape == (2 * B, 3, size, size)
+    for k in range(2):
+        for i, (stack, views, _) in enumerate(items):
+            p = views[k]
+            for resize in (S.resize_aa_bicubic, S.torch_resize):
+                want = S.make_view(stack, p.level, p.width, p.top, p.left, p.h, p.w, p.flip, size, resize=resize)
+                np.testing.assert_allclose(out[k * B + i], want, atol=1e-5, rtol=0, err_msg=f"view {k} sample {i} {p}")
+
+
+@pytest.mark.gpu
+def test_slice_views_full_batch_properties():
+    """BASELINE's batch (256 stacks of 512x512 -> 512 views of 224x224) through size-independent properties: a constant stack
+    maps to the constant (window(c) - mean) / std whatever the crop (weights sum to 1); flipping is an exact mirror; the
+    output of every view is finite and inside the normalised [0,1] range widened by the (two-pass) bicubic overshoot."""
+    from dinox.views import StackBatch, ViewParams, draw_view, make_views
+    B, H, W, size = 256, 512, 512, 224
+    g = torch.Generator().manual_seed(0)
+    raw = torch.randint(22768, 42768, (B, 3, H, W), generator=g, dtype=torch.int32).to(torch.int16)
+    raw[0] = np.int16(32768 + 400 - 65536)                     # sample 0: constant 40 HU (u16 33168 as an int16 bit pattern)
+    random.seed(5)
+    views = [[draw_view(H, W) for _ in range(B)] for _ in range(2)]
+    views[1][1] = ViewParams(views[0][1].level, views[0][1].width, views[0][1].top, views[0][1].left, views[0][1].h, views[0][1].w,
+                             not views[0][1].flip)
+    sb = StackBatch(raw.reshape(-1).to(DEV), [i * 3 * H * W for i in range(B)], [(H, W)] * B, views, torch.ones(B, 3))
+    out = make_views(sb, size)
+    assert out.shape == (2 * B, 3, size, size) and bool(torch.isfinite(out).all())
+    mean, std = torch.tensor(S.MEAN, device=DEV).view(3, 1, 1), torch.tensor(S.STD, device=DEV).view(3, 1, 1)
+    for k in range(2):
+        p = views[k][0]
+        c = float(S.hu_window01(np.array([33168], dtype=np.uint16), p.level, p.width)[0])
+        assert float((out[k * B] - (c - mean) / std).abs().max()) < 2e-6
+    assert torch.equal(out[1], out[B + 1].flip(-1))
+    lo, hi = (0 - 0.485) / 0.229 - 2.0, (1 - 0.406) / 0.225 + 2.0     # white noise is the worst case for the negative lobes
+    assert float(out.min()) >= lo and float(out.max()) <= hi
+
+
+@pytest.mark.gpu
+def test_cli_gpu_views_equals_cpu_views(cli, tmp_path):
+    """The drop-in script with --gpu-views trains on the same views as with its CPU pipeline: same seed, same draws (both
+    consume Python's ``random`` in the same order), so the logged losses agree step by step (fp32 mode, 1e-3)."""
+    import json
+    common = ["--config", "vit-tiny", "--vit-patch", "16", "--vit-dim", "64", "--vit-depth", "2", "--vit-heads", "2", "--out-dim", "256",
+              "--img-size", "32", "--batch-size", "8", "--scale-aware", "--synthetic", "32", "--num-workers", "0", "--warmup-steps", "2",
+              "--lr", "1e-3", "--max-steps", "4", "--ckpt-every", "100"]
+    logs = []
+    for tag, extra in (("cpu", []), ("gpu", ["--gpu-views"])):
+        log = tmp_path / f"{tag}.jsonl"
+        cli.main(common + extra + ["--log-json", str(log), "--run-dir", str(tmp_path / tag)])
+        logs.append([json.loads(l) for l in log.read_text().splitlines()])
+    assert [l["step"] for l in logs[0]] == [0, 1, 2, 3] == [l["step"] for l in logs[1]]
+    for a, b in zip(*logs):
+        assert a["loss"] == pytest.approx(b["loss"], rel=1e-3), (a, b)

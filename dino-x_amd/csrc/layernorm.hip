@@ -287,7 +287,7 @@ extern "C" int64_t dinox_layernorm_bwd_ws_bytes(int64_t rows, int dim) {
 
 extern "C" int dinox_layernorm_bwd(const void* dy, const float* x, const float* w, const float* mean, const float* rstd,
                                    float* dx, const float* dx_add, void* dx_lowp, float* dw, float* db, void* ws,
-                                   int64_t rows, int dim, int dy_dtype, void* stream) {
+                                   int64_t rows, int dim, int dy_dtype, int accumulate, void* stream) {
   DX_REQUIRE(dy && x && w && mean && rstd && dx && dw && db && ws, DINOX_EINVAL, "layernorm_bwd: null pointer");
   DX_REQUIRE(rows > 0 && dim > 0, DINOX_EINVAL, "layernorm_bwd: rows=%lld dim=%d", (long long)rows, dim);
   DX_REQUIRE(dy_dtype == DINOX_F32 || dy_dtype == DINOX_BF16, DINOX_EINVAL, "layernorm_bwd: dtype %d", dy_dtype);
@@ -315,9 +315,11 @@ extern "C" int dinox_layernorm_bwd(const void* dy, const float* x, const float* 
 #undef LN_BWD
   int rc = check_launch("layernorm_bwd");
   if (rc) return rc;
-  hipError_t me = hipMemsetAsync(dw, 0, (size_t)dim * sizeof(float), st);
-  if (me == hipSuccess) me = hipMemsetAsync(db, 0, (size_t)dim * sizeof(float), st);
-  if (me != hipSuccess) return fail((int)me, "layernorm_bwd: memset: %s", hipGetErrorString(me));
+  if (!accumulate) {                       // the reduce kernel adds its partial sums with atomics
+    hipError_t me = hipMemsetAsync(dw, 0, (size_t)dim * sizeof(float), st);
+    if (me == hipSuccess) me = hipMemsetAsync(db, 0, (size_t)dim * sizeof(float), st);
+    if (me != hipSuccess) return fail((int)me, "layernorm_bwd: memset: %s", hipGetErrorString(me));
+  }
   hipLaunchKernelGGL(ln_bwd_reduce, dim3((unsigned)ceil_div(2 * dim, 64), 16), dim3(256), 0, st, wsf, dw, db, parts, dim);
   return check_launch("layernorm_bwd_reduce");
 }

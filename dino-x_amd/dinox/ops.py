@@ -318,8 +318,10 @@ def layernorm_fwd(x: Tensor, w: Tensor, b: Tensor, out_dtype: torch.dtype, eps: 
 
 
 def layernorm_bwd(dy: Tensor, x: Tensor, w: Tensor, mean: Tensor, rstd: Tensor, dx: Optional[Tensor] = None,
-                  dx_add: Optional[Tensor] = None, want_lowp=False):
-    """dx = (dx_add or 0) + LN'(dy); returns (dx, dw, db, bf16 copy of dx or None).  dx may alias dx_add."""
+                  dx_add: Optional[Tensor] = None, want_lowp=False, b: Optional[Tensor] = None):
+    """dx = (dx_add or 0) + LN'(dy); returns (dx, dw, db, bf16 copy of dx or None).  dx may alias dx_add.
+    With the bias parameter ``b`` given and both affine parameters registered in the gradient sink, dw/db are added
+    straight into the gradient arena and returned as None."""
     dy, x = _c(dy), _c(x)
     D = x.shape[-1]
     rows = x.numel() // D
@@ -327,12 +329,18 @@ def layernorm_bwd(dy: Tensor, x: Tensor, w: Tensor, mean: Tensor, rstd: Tensor, 
         dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
     if dx_add is not None:
         assert dx_add.is_contiguous() and dx_add.dtype == torch.float32 and dx_add.numel() == x.numel()
-    dw = torch.empty(D, dtype=torch.float32, device=x.device)
-    db = torch.empty(D, dtype=torch.float32, device=x.device)
+    sw, sb = (grad_sink.lookup(w), grad_sink.lookup(b)) if b is not None else (None, None)
+    sunk = sw is not None and sb is not None
+    dw = sw[1].grad if sunk else torch.empty(D, dtype=torch.float32, device=x.device)
+    db = sb[1].grad if sunk else torch.empty(D, dtype=torch.float32, device=x.device)
     lowp = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if want_lowp else None
     ws = torch.empty(lib.dinox_layernorm_bwd_ws_bytes(rows, D), dtype=torch.uint8, device=x.device)
     check(lib.dinox_layernorm_bwd(_p(dy), _p(x), _p(w), _p(mean), _p(rstd), _p(dx), _p(dx_add), _p(lowp), _p(dw), _p(db), _p(ws),
-                                  rows, D, _code(dy.dtype), _stream()), "dinox_layernorm_bwd")
+                                  rows, D, _code(dy.dtype), int(sunk), _stream()), "dinox_layernorm_bwd")
+    if sunk:
+        grad_sink.ready(sw)
+        grad_sink.ready(sb)
+        return dx, None, None, lowp
     return dx, dw, db, lowp
 
 
@@ -368,14 +376,16 @@ class LayerNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, out_dtype, eps):
         y, mean, rstd = layernorm_fwd(x, w, b, out_dtype, eps)
-        ctx.save_for_backward(x, w, mean, rstd)
+        ctx.save_for_backward(x, w, mean, rstd, b)
         ctx.mode_bf16 = current_dtype() == torch.bfloat16
+        if ctx.needs_input_grad[1]:
+            grad_sink.use(w, b)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w, mean, rstd = ctx.saved_tensors
-        dx, dw, db, lowp = layernorm_bwd(dy, x, w, mean, rstd, want_lowp=ctx.mode_bf16)
+        x, w, mean, rstd, b = ctx.saved_tensors
+        dx, dw, db, lowp = layernorm_bwd(dy, x, w, mean, rstd, want_lowp=ctx.mode_bf16, b=b if ctx.needs_input_grad[1] else None)
         if lowp is not None:
             lowp_cache.put(dx, lowp)
         return dx, dw, db, None, None
@@ -508,14 +518,15 @@ class BlockFn(torch.autograd.Function):
         x2 = gemm(act, weight_operand(w2, dt), bias=b2, residual=x1, out_dtype=torch.float32)
         if train:
             ctx.save_for_backward(x0, x1, xn1, xn2, qkv, o, lse, pre, act, mean1, rstd1, mean2, rstd2, n1w, n2w, wqkv, wproj, w1, w2,
-                                  bqkv, bproj, b1, b2)
+                                  bqkv, bproj, b1, b2, n1b, n2b)
             ctx.dt, ctx.heads, ctx.shape = dt, heads, (V, N, D)
-            grad_sink.use(wqkv, bqkv, wproj, bproj, w1, b1, w2, b2)
+            grad_sink.use(wqkv, bqkv, wproj, bproj, w1, b1, w2, b2, n1w, n1b, n2w, n2b)
         return x2.view(V, N, D)
 
     @staticmethod
     def backward(ctx, g):
-        x0, x1, xn1, xn2, qkv, o, lse, pre, act, mean1, rstd1, mean2, rstd2, n1w, n2w, wqkv, wproj, w1, w2, bqkv, bproj, b1, b2 = ctx.saved_tensors
+        (x0, x1, xn1, xn2, qkv, o, lse, pre, act, mean1, rstd1, mean2, rstd2, n1w, n2w, wqkv, wproj, w1, w2, bqkv, bproj, b1, b2,
+         n1b, n2b) = ctx.saved_tensors
         dt, heads = ctx.dt, ctx.heads
         V, N, D = ctx.shape
         M = V * N
@@ -535,7 +546,7 @@ class BlockFn(torch.autograd.Function):
         dxn2 = gemm(dpre, b, out_dtype=dt, **kw)
         dw1, db1 = weight_grad(dpre, xn2.view(M, D), w1, b1, b1 is not None)
         del dpre
-        g1, dn2w, dn2b, g1_lp = layernorm_bwd(dxn2, x1, n2w, mean2, rstd2, dx_add=g.view(M, D), want_lowp=bf)   # g1 = g + LN2'(.)
+        g1, dn2w, dn2b, g1_lp = layernorm_bwd(dxn2, x1, n2w, mean2, rstd2, dx_add=g.view(M, D), want_lowp=bf, b=n2b)   # g1 = g + LN2'(.)
         g1_op = g1_lp if bf else g1
         # ---- attention: x1 = x0 + proj(attn(qkv(xn1)))
         b, kw = wt(wproj)
@@ -545,7 +556,7 @@ class BlockFn(torch.autograd.Function):
         b, kw = wt(wqkv)
         dxn1 = gemm(dqkv, b, out_dtype=dt, **kw)
         dwq, dbq = weight_grad(dqkv, xn1.view(M, D), wqkv, bqkv, bqkv is not None)
-        g0, dn1w, dn1b, g0_lp = layernorm_bwd(dxn1, x0, n1w, mean1, rstd1, dx=g1, dx_add=g1, want_lowp=bf)      # in place on our own g1
+        g0, dn1w, dn1b, g0_lp = layernorm_bwd(dxn1, x0, n1w, mean1, rstd1, dx=g1, dx_add=g1, want_lowp=bf, b=n1b)      # in place on our own g1
         g0 = g0.view(V, N, D)
         if g0_lp is not None:
             lowp_cache.put(g0, g0_lp.view(V, N, D))

@@ -109,7 +109,8 @@ int dinox_colsum(const void* x, float* out, int64_t M, int64_t N, int64_t ldx, i
  * LayerNorm -- replaces nn.LayerNorm(D), eps 1e-5, affine (zoo/arch.py:89,91,126,187; calls :95,96,237).
  * x is the fp32 residual stream; y is written in out_dtype (bf16 when it only feeds a GEMM).
  * bwd: dx = (dx_add ? dx_add : 0) + LN'(dy)  -- dx_add is the gradient arriving over the skip connection of the
- *      pre-norm block (may be NULL, may alias dx);  dw, db overwritten.  ws: dinox_layernorm_bwd_ws_bytes(rows, dim) bytes.
+ *      pre-norm block (may be NULL, may alias dx);  dw, db overwritten, or added to when accumulate != 0 (gradient
+ *      arena).  ws: dinox_layernorm_bwd_ws_bytes(rows, dim) bytes.
  *      dx_lowp (optional, may be NULL): bf16 copy of the final dx -- the residual-stream gradient is the
  *      dY operand of the next backward GEMMs, which autocast rounds to bf16 at that point as well.
  * ------------------------------------------------------------------------------------------ */
@@ -118,7 +119,7 @@ int dinox_layernorm_fwd(const float* x, const float* w, const float* b, void* y,
 int64_t dinox_layernorm_bwd_ws_bytes(int64_t rows, int dim);
 int dinox_layernorm_bwd(const void* dy, const float* x, const float* w, const float* mean, const float* rstd,
                         float* dx, const float* dx_add, void* dx_lowp, float* dw, float* db, void* ws,
-                        int64_t rows, int dim, int dy_dtype, void* stream);
+                        int64_t rows, int dim, int dy_dtype, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Multi-head self-attention core -- replaces the reshape/permute/unbind +

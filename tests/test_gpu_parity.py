@@ -701,7 +701,9 @@ def test_grad_sink_accumulates_in_place(dx, mode):
     from dinox.engine import flatten_parameters
     dt = torch.float32 if mode == "fp32" else torch.bfloat16
     torch.manual_seed(5)
-    lin = arch.Linear(64, 136).to(DEV)
+    lin = torch.nn.Sequential(arch.LayerNorm(64), arch.Linear(64, 136)).to(DEV)      # LayerNorm's affine gradients use the sink too
+    with torch.no_grad():
+        lin[0].weight.add_(0.1 * torch.randn(64, device=DEV))
     x = torch.randn(300, 64, device=DEV)
 
     def run(sink):
@@ -727,7 +729,7 @@ def test_grad_sink_accumulates_in_place(dx, mode):
 
     ref, _ = run(False)
     got, events = run(True)
-    assert sorted(events) == [0, 0, 1, 1]                                # weight and bias announced once per backward
+    assert sorted(events) == [0, 0, 1, 1, 2, 2, 3, 3]                    # every parameter announced once per backward
     assert rel_l2(got, ref) < (1e-6 if mode == "fp32" else 1e-5)
 
 

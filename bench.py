@@ -40,12 +40,12 @@ import torch.distributed as dist  # noqa: E402
 PEAK_BF16_DENSE_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16 MFMA
 
 
-def fwd_flops_per_image(img=224, patch=16, dim=384, depth=12, out_dim=8192, regs=4):
-    """BASELINE.md section 2 / SURVEY.md 8d: F_fwd per image."""
+def fwd_flops_per_image(img=224, patch=16, dim=384, depth=12, out_dim=8192, regs=4, gram=True):
+    """BASELINE.md section 2 / SURVEY.md 8d: F_fwd per image (gram=False: a view that does not enter the Gram term)."""
     P = (img // patch) ** 2
     N = 1 + P + regs
     blk = N * dim * 3 * dim + 2 * N * N * dim + N * dim * dim + 8 * N * dim * dim
-    return 2.0 * (P * 3 * patch * patch * dim + depth * blk + dim * dim + dim * out_dim + (N - 1) ** 2 * dim)
+    return 2.0 * (P * 3 * patch * patch * dim + depth * blk + dim * dim + dim * out_dim + ((N - 1) ** 2 * dim if gram else 0))
 
 
 def cpu_baseline(cfg_kw, out_dim, seconds_budget=25.0):
@@ -86,6 +86,9 @@ def main() -> None:
     ap.add_argument("--fp32", action="store_true", help="parity mode (exact-fp32 MFMA) instead of bf16")
     ap.add_argument("--model", choices=["vit-small", "vit-large"], default="vit-small",
                     help="vit-small = BASELINE configs[2] (the metric's config); vit-large = configs[4] shape (not the headline metric)")
+    ap.add_argument("--local-crops", type=int, default=0,
+                    help="multi-crop extension (not in the reference, whose loop has 2 global views): L extra student-only local views per sample")
+    ap.add_argument("--local-size", type=int, default=96)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket GEMM launches with HIP events")
     args = ap.parse_args()
@@ -123,6 +126,9 @@ def main() -> None:
     batch = torch.randn(2 * B, 3, 224, 224, generator=g).to(dev)
     sp = (torch.rand(B, 3, generator=g) * torch.tensor([0.52, 0.52, 4.375]) + torch.tensor([0.46, 0.46, 0.625]))
     sp2 = torch.cat([sp, sp], 0).to(dev)
+    L = args.local_crops
+    loc = torch.randn(L * B, 3, args.local_size, args.local_size, generator=g).to(dev) if L else None
+    spl = torch.cat([sp] * L, 0).to(dev) if L else None
 
     T_START = time.perf_counter()
 
@@ -138,7 +144,7 @@ def main() -> None:
 
     note(f"model + data resident (world {world}, B {B}/GPU, {'fp32' if args.fp32 else 'bf16'})")
     for i in range(args.warmup):
-        eng.step(batch, sp2)
+        eng.step(batch, sp2, loc, spl)
         torch.cuda.synchronize()
         note(f"warm-up step {i} done")
     timer = None
@@ -148,7 +154,7 @@ def main() -> None:
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        eng.step(batch, sp2)
+        eng.step(batch, sp2, loc, spl)
     barrier()
     dt = time.perf_counter() - t0
     ops.GEMM_TIMER = None
@@ -165,6 +171,8 @@ def main() -> None:
     if rank == 0:
         samples_s = world * B * args.steps / dt
         gf_sample = 8.0 * fwd_flops_per_image(dim=cfg_kw["dim"], depth=cfg_kw["depth"]) / 1e9
+        if L:                                  # student fwd + bwd (3x fwd) of every local view; the Gram term does not see them
+            gf_sample += 3.0 * L * fwd_flops_per_image(img=args.local_size, dim=cfg_kw["dim"], depth=cfg_kw["depth"], gram=False) / 1e9
         step_tflops = samples_s * gf_sample / 1e3 / world          # per GPU
         roof = {"bound": "mfma", "achieved": None, "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None}
         if kernels:
@@ -182,7 +190,7 @@ def main() -> None:
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
             fam = "dinox::" + roof.get("kernel", "")
-            if fam in pmc and args.model == "vit-small" and B == 256:
+            if fam in pmc and args.model == "vit-small" and B == 256 and not L:
                 roof["traffic"] = pmc[fam]["hbm_bytes_per_launch"]
                 roof["traffic_note"] = "avg HBM bytes/launch, profiles/r01_pmc_traffic.json; algorithmic avg ~447e6 (operands+outputs once)"
         except (OSError, ValueError, KeyError):
@@ -190,14 +198,15 @@ def main() -> None:
         roof["step"] = {"gflop_per_sample": round(gf_sample, 2), "achieved": round(step_tflops, 2),
                         "frac": round(step_tflops / PEAK_BF16_DENSE_TFLOPS, 4)}
         line = {
-            "metric": "training images/sec (source samples; 2 global views each) ViT-S/16 224px bs256/GPU" if args.model == "vit-small"
+            "metric": (f"training images/sec (source samples; 2 global + {L} local {args.local_size}px views each; multi-crop extension, the reference has 2 global views) ViT-S/16 224px bs{B}/GPU" if L else
+                       "training images/sec (source samples; 2 global views each) ViT-S/16 224px bs256/GPU") if args.model == "vit-small"
             else "training images/sec (source samples; 2 global views each) ViT-L/16 224px (configs[4] shape, not the headline metric)",
             "value": round(samples_s, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.fp32 else "bf16", "data": "synthetic",
-            "config": {"workload": ("ViT-S" if args.model == "vit-small" else "ViT-L") + "/16 224x224x3 2.5D slice stacks, scale-aware, 2 views/sample, DINO+Gram loss, AdamW+EMA",
-                       "per_gpu_batch": B, "global_batch": B * world, "views_per_step": 2 * B * world, "tokens": 201, "out_dim": out_dim,
-                       "parallelism": f"dp{world}", "views_per_s": round(2 * samples_s, 2),
+            "config": {"workload": ("ViT-S" if args.model == "vit-small" else "ViT-L") + f"/16 224x224x3 2.5D slice stacks, scale-aware, {'2 views/sample' if not L else f'2 global + {L} local {args.local_size}px views/sample'}, DINO+Gram loss, AdamW+EMA",
+                       "per_gpu_batch": B, "global_batch": B * world, "views_per_step": (2 + L) * B * world, "local_crops": L, "tokens": 201, "out_dim": out_dim,
+                       "parallelism": f"dp{world}", "views_per_s": round((2 + L) * samples_s, 2),
                        "loss": round(scal["loss"], 5), "grad_norm": round(scal["grad_norm"], 5)},
             "roofline": roof,
         }

@@ -45,6 +45,59 @@ __global__ __launch_bounds__(CE_THREADS) void dino_ce_kernel(const float* __rest
   if (threadIdx.x == 0) row_loss[i] = acc;
 }
 
+// Multi-crop form (extension, not in the reference: DINO paper Alg. 1 with local crops).  Student rows are view-major
+// [(G+L) views][B samples], the first G views are the global ones the teacher also saw; teacher rows [G][B].
+// One workgroup per student row (v, b):  row_loss = sum_{q < G, q != v} -sum_k p_q[k] (z[k] - lse),  z = s/ts,
+// p_q = softmax((t[q][b] - c)/tt);   ds = gscale/(B*terms) * (n_q softmax(z) - sum_q p_q)/ts,  n_q = #{q != v}.
+// G = 2, L = 0 is dino_ce_kernel.  The teacher's max / sum-exp per row come from dino_teacher_stats_kernel.
+__global__ __launch_bounds__(CE_THREADS) void dino_teacher_stats_kernel(const float* __restrict__ t, const float* __restrict__ center,
+                                                                        float inv_tt, float* __restrict__ tmax, float* __restrict__ tinv, int K) {
+  __shared__ float red[16];
+  const int i = blockIdx.x;
+  const float* tr = t + (int64_t)i * K;
+  float m = -INFINITY;
+  for (int k = threadIdx.x; k < K; k += CE_THREADS) m = fmaxf(m, (tr[k] - center[k]) * inv_tt);
+  m = block_max(m, red);
+  float a = 0.f;
+  for (int k = threadIdx.x; k < K; k += CE_THREADS) a += expf((tr[k] - center[k]) * inv_tt - m);
+  a = block_sum(a, red);
+  if (threadIdx.x == 0) {
+    tmax[i] = m;
+    tinv[i] = 1.0f / a;
+  }
+}
+
+__global__ __launch_bounds__(CE_THREADS) void dino_ce_multi_kernel(const float* __restrict__ s, const float* __restrict__ t,
+                                                                   const float* __restrict__ center, const float* __restrict__ tmax,
+                                                                   const float* __restrict__ tinv, float inv_ts, float inv_tt, float gscale,
+                                                                   float* __restrict__ ds, float* __restrict__ row_loss, int B, int G, int K) {
+  __shared__ float red[16];
+  const int i = blockIdx.x, v = i / B, b = i % B;
+  const float* sr = s + (int64_t)i * K;
+  float ms = -INFINITY;
+  for (int k = threadIdx.x; k < K; k += CE_THREADS) ms = fmaxf(ms, sr[k] * inv_ts);
+  ms = block_max(ms, red);
+  float ss = 0.f;
+  for (int k = threadIdx.x; k < K; k += CE_THREADS) ss += expf(sr[k] * inv_ts - ms);
+  ss = block_sum(ss, red);
+  const float log_ss = logf(ss), inv_ss = 1.0f / ss;
+  const int nq = v < G ? G - 1 : G;
+  float acc = 0.f;
+  for (int k = threadIdx.x; k < K; k += CE_THREADS) {
+    const float zs = sr[k] * inv_ts - ms;
+    float tp = 0.f;
+    for (int q = 0; q < G; ++q) {
+      if (q == v) continue;
+      const int tr = q * B + b;
+      tp += expf((t[(int64_t)tr * K + k] - center[k]) * inv_tt - tmax[tr]) * tinv[tr];
+    }
+    acc -= tp * (zs - log_ss);
+    if (ds) ds[(int64_t)i * K + k] = gscale * ((float)nq * expf(zs) * inv_ss - tp) * inv_ts;
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) row_loss[i] = acc;
+}
+
 // loss[0] = scale * sum(x[0..n))  -- single workgroup, deterministic order.
 __global__ __launch_bounds__(256) void final_sum_kernel(const float* __restrict__ x, int n, float scale, float* __restrict__ out) {
   __shared__ float red[16];
@@ -148,6 +201,32 @@ extern "C" int dinox_dino_ce(const float* s, const float* t, const float* center
   if (rc) return rc;
   hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, st, row_loss, rows2B, 1.0f / (float)rows2B, loss);
   return check_launch("dino_ce_sum");
+}
+
+extern "C" int dinox_dino_ce_multi(const float* s, const float* t, const float* center, float student_temp, float teacher_temp,
+                                   float grad_scale, float* loss, float* ds, float* ws, int B, int n_global, int n_views, int K,
+                                   void* stream) {
+  DX_REQUIRE(s && t && center && loss && ws, DINOX_EINVAL, "dino_ce_multi: null pointer");
+  DX_REQUIRE(B >= 1 && n_global >= 1 && n_views >= n_global && n_views >= 2 && K > 0, DINOX_EINVAL,
+             "dino_ce_multi: B=%d global=%d views=%d K=%d", B, n_global, n_views, K);
+  DX_REQUIRE(student_temp > 0.f && teacher_temp > 0.f, DINOX_EINVAL, "dino_ce_multi: temperatures must be > 0");
+  DX_REQUIRE((int64_t)n_views * B <= 0x7fffffff, DINOX_EINVAL, "dino_ce_multi: too many rows");
+  hipStream_t st = as_stream(stream);
+  const int srows = n_views * B, trows = n_global * B;
+  const int terms = n_global * (n_views - 1);
+  float* row_loss = ws;                   // [srows]
+  float* tmax = ws + srows;               // [trows]
+  float* tinv = tmax + trows;             // [trows]
+  hipLaunchKernelGGL(dino_teacher_stats_kernel, dim3(trows), dim3(CE_THREADS), 0, st, t, center, 1.0f / teacher_temp, tmax, tinv, K);
+  int rc = check_launch("dino_teacher_stats");
+  if (rc) return rc;
+  const float norm = 1.0f / ((float)B * (float)terms);
+  hipLaunchKernelGGL(dino_ce_multi_kernel, dim3(srows), dim3(CE_THREADS), 0, st, s, t, center, tmax, tinv, 1.0f / student_temp,
+                     1.0f / teacher_temp, grad_scale * norm, ds, row_loss, B, n_global, K);
+  rc = check_launch("dino_ce_multi");
+  if (rc) return rc;
+  hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, st, row_loss, srows, norm, loss);
+  return check_launch("dino_ce_multi_sum");
 }
 
 extern "C" int dinox_colmean(const float* t, float* out, int rows, int K, void* stream) {

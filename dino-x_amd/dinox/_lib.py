@@ -51,6 +51,7 @@ SIGNATURES = {
     "dinox_scale_embed_bwd_ws_bytes": (i64, [i32, i32, i32]),
     "dinox_scale_embed_bwd": (i32, [vp] * 17 + [i32, i32, i32, vp]),
     "dinox_dino_ce": (i32, [vp, vp, vp, f32, f32, f32, vp, vp, vp, i32, i32, vp]),
+    "dinox_dino_ce_multi": (i32, [vp, vp, vp, f32, f32, f32, vp, vp, vp, i32, i32, i32, i32, vp]),
     "dinox_colmean": (i32, [vp, vp, i32, i32, vp]),
     "dinox_center_ema": (i32, [vp, vp, f32, i32, vp]),
     "dinox_gram_normalize": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),

@@ -114,9 +114,13 @@ class TrainEngine:
         self.last = {}
 
     # -- one optimiser step ---------------------------------------------------------------------
-    def step(self, batch: torch.Tensor, spacing2b: Optional[torch.Tensor] = None) -> dict:
+    def step(self, batch: torch.Tensor, spacing2b: Optional[torch.Tensor] = None, local_batch: Optional[torch.Tensor] = None,
+             local_spacing: Optional[torch.Tensor] = None) -> dict:
         """batch: (2B,3,H,W) = [view1; view2] on the device; spacing2b: (2B,3) or None.
-        Returns device tensors {loss, dino, gram, grad_norm_sq} and the python float lr (no sync)."""
+        local_batch (L*B,3,s,s), view-major, with local_spacing (L*B,3): the multi-crop extension (not in the reference) --
+        the student also sees L smaller crops per sample, which enter the DINO term only (every (teacher view, other student
+        view) pair, averaged); Gram and KoLeo stay on the global views.
+        Returns device tensors {loss, dino, gram, koleo, grad_norm_sq} and the python float lr (no sync)."""
         hp = self.hp
         lr = get_lr(self.step_count, hp.max_steps, hp.warmup_steps, hp.lr, hp.min_lr)
         # gradient accumulation with the reference's semantics (phase5_big_run.py:1769-1796): `step` counts micro-batches,
@@ -151,8 +155,14 @@ class TrainEngine:
                 with torch.no_grad():
                     t_feats = self.teacher.backbone(batch, spacing=spacing2b)
                     t_out = self.teacher.head(t_feats[:, 0])
-            s_out = self.student.head(s_feats[:, 0])
-            l_dino = ops.DinoCEFn.apply(s_out, t_out, self.center, hp.student_temp, hp.teacher_temp)
+            if local_batch is None:
+                s_out = self.student.head(s_feats[:, 0])
+                l_dino = ops.DinoCEFn.apply(s_out, t_out, self.center, hp.student_temp, hp.teacher_temp)
+            else:
+                l_feats = self.student.backbone(local_batch, spacing=local_spacing)
+                s_all = self.student.head(torch.cat([s_feats[:, 0], l_feats[:, 0]], 0))       # one head product for all views
+                s_out = s_all[:s_feats.shape[0]]
+                l_dino = ops.DinoCEMultiFn.apply(s_all, t_out, self.center, hp.student_temp, hp.teacher_temp, 2)
             # centre EMA after the loss used the old centre; batch mean is global under DP
             bm = all_reduce_mean_(ops.colmean(t_out), self.group)
             ops.center_ema_(self.center.view(-1), bm, hp.center_momentum)

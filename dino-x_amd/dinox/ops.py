@@ -790,6 +790,94 @@ class DinoCEFn(torch.autograd.Function):
         return (ds * g).to(ctx.sdtype), None, None, None, None
 
 
+class DinoCEMultiFn(torch.autograd.Function):
+    """Multi-crop DINO cross-entropy (extension; the reference has 2 global views only): student rows view-major
+    [(G+L) views][B], globals first; teacher rows [G][B]; mean over every (teacher view, other student view) pair.
+    G = 2, L = 0 equals DinoCEFn."""
+
+    @staticmethod
+    def forward(ctx, s, t, center, student_temp, teacher_temp, n_global):
+        _need_cuda(s, t, center)
+        sf, tf = _c(s.float()), _c(t.float())
+        K = sf.shape[1]
+        B = tf.shape[0] // n_global
+        n_views = sf.shape[0] // B
+        assert tf.shape[0] == n_global * B and sf.shape[0] == n_views * B and tf.shape[1] == K, (tuple(s.shape), tuple(t.shape), n_global)
+        loss = torch.empty(1, dtype=torch.float32, device=sf.device)
+        ds = torch.empty_like(sf) if ctx.needs_input_grad[0] else None
+        ws = torch.empty((n_views + 2 * n_global) * B, dtype=torch.float32, device=sf.device)
+        check(lib.dinox_dino_ce_multi(_p(sf), _p(tf), _p(_c(center).reshape(-1)), student_temp, teacher_temp, 1.0, _p(loss), _p(ds), _p(ws),
+                                      B, n_global, n_views, K, _stream()), "dinox_dino_ce_multi")
+        ctx.save_for_backward(ds)
+        ctx.sdtype = s.dtype
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (ds,) = ctx.saved_tensors
+        return (ds * g).to(ctx.sdtype), None, None, None, None, None
+
+
+_POS_W: dict = {}
+
+
+def _bicubic_matrix_1d(n_in: int, n_out: int):
+    """[n_out][n_in] weights of torch's non-antialiased bicubic resize (align_corners=False, Keys cubic A = -0.75, border
+    replication): what F.interpolate(mode="bicubic") applies along one axis."""
+    A = -0.75
+    rows = [[0.0] * n_in for _ in range(n_out)]
+    scale = n_in / n_out
+    for i in range(n_out):
+        x = (i + 0.5) * scale - 0.5
+        ix = math.floor(x)
+        t = x - ix
+        w = (((A * (t + 1) - 5 * A) * (t + 1) + 8 * A) * (t + 1) - 4 * A,
+             ((A + 2) * t - (A + 3)) * t * t + 1,
+             ((A + 2) * (1 - t) - (A + 3)) * (1 - t) * (1 - t) + 1,
+             ((A * (2 - t) - 5 * A) * (2 - t) + 8 * A) * (2 - t) - 4 * A)
+        for k in range(4):
+            rows[i][min(max(ix - 1 + k, 0), n_in - 1)] += w[k]
+    return rows
+
+
+class PosInterpFn(torch.autograd.Function):
+    """Position embedding of a crop whose patch grid differs from the model's (multi-crop extension; the reference adds
+    ``pos_embed`` as is and cannot take another input size): the CLS entry is kept, the g x g patch grid is resized to
+    g_out x g_out by bicubic interpolation, written as ONE fp32 product with the constant [g_out^2, g^2] weight matrix
+    (kron of the two 1-D bicubic matrices); backward is the transposed product."""
+
+    @staticmethod
+    def forward(ctx, pos, g_out):
+        _need_cuda(pos)
+        P_in, D = pos.shape[1] - 1, pos.shape[2]
+        g_in = int(round(math.sqrt(P_in)))
+        assert g_in * g_in == P_in, "position grid must be square"
+        key = (g_in, g_out, pos.device)
+        W = _POS_W.get(key)
+        if W is None:
+            m = torch.tensor(_bicubic_matrix_1d(g_in, g_out), dtype=torch.float64)
+            W = _POS_W[key] = torch.kron(m, m).float().to(pos.device).contiguous()
+        out = torch.empty((1, 1 + g_out * g_out, D), dtype=torch.float32, device=pos.device)
+        pf = _c(pos.detach().float())
+        out[0, :1].copy_(pf[0, :1])
+        gemm(W, pf[0, 1:], transB=True, out=out[0, 1:])
+        ctx.W = W
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        W = ctx.W
+        g = _c(g.float())
+        dpos = torch.empty((1, 1 + W.shape[1], g.shape[2]), dtype=torch.float32, device=g.device)
+        dpos[0, :1].copy_(g[0, :1])
+        gemm(W, g[0, 1:], transA=True, transB=True, out=dpos[0, 1:])
+        return dpos, None
+
+
+def interp_pos(pos: Tensor, g_out: int) -> Tensor:
+    return PosInterpFn.apply(pos, g_out)
+
+
 def colmean(t: Tensor) -> Tensor:
     t = _c(t.float())
     out = torch.empty(t.shape[1], dtype=torch.float32, device=t.device)

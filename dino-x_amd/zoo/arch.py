@@ -212,8 +212,13 @@ class PatchViT(nn.Module):
         if self.scale_aware and spacing is not None:
             scale = self.scale_embed(spacing)
         regs = self.registers if self.num_registers > 0 else None
-        t = ops.TokensFn.apply(x, self.patch_embed.weight, self.patch_embed.bias, self.cls_token, self.pos_embed, regs,
-                               scale, self.patch)
+        pos = self.pos_embed
+        g = x.shape[-1] // self.patch
+        if x.shape[-2] != x.shape[-1] or x.shape[-1] % self.patch:
+            raise ValueError(f"input {tuple(x.shape[-2:])} is not a square multiple of the {self.patch}-pixel patch")
+        if g * g != pos.shape[1] - 1:       # extension (multi-crop local views): the reference has one input size only
+            pos = ops.interp_pos(pos, g)
+        t = ops.TokensFn.apply(x, self.patch_embed.weight, self.patch_embed.bias, self.cls_token, pos, regs, scale, self.patch)
         for blk in self.blocks:
             if self.use_grad_checkpoint and self.training:
                 t = torch.utils.checkpoint.checkpoint(blk, t, use_reentrant=False)

@@ -175,6 +175,13 @@ int dinox_scale_embed_bwd(const float* dout, const float* spacing, const float* 
  * ------------------------------------------------------------------------------------------ */
 int dinox_dino_ce(const float* s, const float* t, const float* center, float student_temp, float teacher_temp,
                   float grad_scale, float* loss, float* ds, float* row_loss, int rows2B, int K, void* stream);
+/* Multi-crop form (an extension: the reference trains on 2 global views only).  s: [n_views][B][K] student logits, view-major,
+ * the first n_global views being the ones the teacher saw; t: [n_global][B][K].  Every pair (teacher view q, student view
+ * v != q) contributes mean_b of the cross-entropy above; loss[0] = their average over the n_global*(n_views-1) pairs.
+ * n_global = n_views = 2 is dinox_dino_ce.  ws: (n_views + 2 n_global) * B floats. */
+int dinox_dino_ce_multi(const float* s, const float* t, const float* center, float student_temp, float teacher_temp,
+                        float grad_scale, float* loss, float* ds, float* ws, int B, int n_global, int n_views, int K,
+                        void* stream);
 int dinox_colmean(const float* t, float* out, int rows, int K, void* stream);
 int dinox_center_ema(float* center, const float* batch_mean, float momentum, int K, void* stream);
 

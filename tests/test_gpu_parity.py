@@ -827,3 +827,94 @@ def test_grad_checkpoint_matches_plain(dx):
     assert grads[0].keys() == grads[1].keys()
     for n in grads[0]:
         assert torch.allclose(grads[0][n], grads[1][n], rtol=1e-5, atol=1e-8), n
+
+
+# ------------------------------------------------------------------------------------------ multi-crop extension
+def test_dino_ce_multi_reduces_to_reference_two_view_loss(dx):
+    """The multi-crop cross-entropy with no local crops must BE the reference-pinned 2-view loss (same value, same gradient)."""
+    ops, _ = dx
+    g = load_golden("dino_loss.npz")
+    s = t(g["s"]).to(DEV).requires_grad_(True)
+    tt, c = t(g["t"]).to(DEV), t(g["center0"]).to(DEV)
+    l = ops.DinoCEMultiFn.apply(s, tt, c, 0.1, 0.04, 2)
+    l.backward()
+    assert float(l) == pytest.approx(float(g["loss1"]), rel=1e-5)
+    close(s.grad, g["ds1"], 1e-4, 1e-8, "ds (multi, L=0)")
+
+
+def test_dino_ce_multi_vs_oracle(dx):
+    ops, _ = dx
+    from oracle import dinox_oracle as O
+    g = torch.Generator().manual_seed(13)
+    B, K, G, L = 5, 1000, 2, 3
+    s = (3 * torch.randn((G + L) * B, K, generator=g))
+    tt, c = 1.5 * torch.randn(G * B, K, generator=g), 0.1 * torch.randn(1, K, generator=g)
+    so = s.clone().requires_grad_(True)
+    lo = O.dino_loss_multicrop(so, tt, c, 0.1, 0.04)
+    lo.backward()
+    sg = s.to(DEV).requires_grad_(True)
+    lg = ops.DinoCEMultiFn.apply(sg, tt.to(DEV), c.to(DEV), 0.1, 0.04, 2)
+    (2.0 * lg).backward()
+    assert float(lg) == pytest.approx(float(lo), rel=1e-5)
+    assert rel_l2(sg.grad, 2.0 * so.grad) < 1e-5
+
+
+@pytest.mark.parametrize("g_in,g_out", [(14, 6), (4, 2), (4, 9)])
+def test_pos_interp_matches_torch_bicubic(dx, g_in, g_out):
+    """ops.interp_pos == F.interpolate(bicubic, align_corners=False) on the patch grid, CLS entry untouched; backward is the
+    transposed map (checked against autograd through F.interpolate)."""
+    import torch.nn.functional as F
+    ops, _ = dx
+    g = torch.Generator().manual_seed(g_in * 10 + g_out)
+    D = 24
+    pos = torch.randn(1, 1 + g_in * g_in, D, generator=g)
+    up = torch.randn(1, 1 + g_out * g_out, D, generator=g)
+    pr = pos.clone().requires_grad_(True)
+    grid = pr[0, 1:].reshape(g_in, g_in, D).permute(2, 0, 1)[None]
+    ref = torch.cat([pr[:, :1], F.interpolate(grid, size=(g_out, g_out), mode="bicubic", align_corners=False)[0].permute(1, 2, 0).reshape(1, -1, D)], 1)
+    (ref * up).sum().backward()
+    pg = pos.to(DEV).requires_grad_(True)
+    out = ops.interp_pos(pg, g_out)
+    (out * up.to(DEV)).sum().backward()
+    close(out, ref.detach(), 1e-5, 2e-6, "interp fwd")
+    close(pg.grad, pr.grad, 1e-5, 2e-6, "interp bwd")
+
+
+def test_step_multicrop_matches_oracle(dx):
+    """One engine step with 2 global (56 px) + 3 local (28 px) views per sample against the oracle's statement of the DINO-paper
+    multi-crop step: loss terms, grad-norm, every parameter gradient.  Parameters are used by two forward passes here, which is
+    also what exercises the gradient sink's use counting."""
+    ops, arch = dx
+    from dinox.engine import StepHyperParams, TrainEngine
+    from oracle import dinox_oracle as O
+    cfg = O.VitCfg(img_size=56, patch=14, dim=64, depth=2, heads=2, num_registers=4, scale_aware=True, out_dim=128)
+    st = O.init_state(cfg, O.random_params(cfg, seed=8))
+    g = torch.Generator().manual_seed(9)
+    B, L = 4, 3
+    batch = torch.randn(2 * B, 3, 56, 56, generator=g)
+    locs = torch.randn(L * B, 3, 28, 28, generator=g)
+    sp = torch.rand(B, 3, generator=g) + 0.5
+    sp2, spl = torch.cat([sp, sp], 0), torch.cat([sp] * L, 0)
+    hp_o = O.HyperParams(lr=1e-3, warmup_steps=1, max_steps=10, ema=0.99)
+    sd = {k: v.clone() for k, v in st.student.items()}
+    st.teacher = {k: v + 0.01 * torch.randn(v.shape, generator=g) for k, v in st.teacher.items()}
+    tsd = {k: v.clone() for k, v in st.teacher.items()}
+    want = O.train_step(st, batch, sp2, hp_o, local_batch=locs, local_spacing=spl)
+    kw = dict(img_size=56, patch=14, dim=64, depth=2, heads=2, num_registers=4, scale_aware=True)
+    student = arch.DinoStudentTeacher(arch.PatchViT(**kw), 128)
+    teacher = arch.DinoStudentTeacher(arch.PatchViT(**kw), 128)
+    student.load_state_dict(sd)
+    teacher.load_state_dict(tsd)
+    eng = TrainEngine(student.to(DEV), teacher.to(DEV), 128, StepHyperParams(lr=1e-3, warmup_steps=1, max_steps=10, ema=0.99))
+    eng.step(batch.to(DEV), sp2.to(DEV), local_batch=locs.to(DEV), local_spacing=spl.to(DEV))
+    got = eng.scalars()
+    for k in ("loss", "dino", "gram", "grad_norm"):
+        assert got[k] == pytest.approx(want[k], rel=1e-3), (k, got[k], want[k])
+    names = [n for n, _ in student.named_parameters()]
+    for n, p in zip(names, eng.params):
+        ref = want["grads"][n]
+        if float(ref.abs().max()) > 1e-6:
+            assert rel_l2(p.grad, ref) < 2e-3, n
+    # without local crops the same engine gives the plain reference step (the extension changes nothing by being there)
+    eng2 = TrainEngine(student.to(DEV), teacher.to(DEV), 128, StepHyperParams(lr=1e-3, warmup_steps=1, max_steps=10, ema=0.99))
+    assert torch.isfinite(eng2.step(batch.to(DEV), sp2.to(DEV))["loss"])

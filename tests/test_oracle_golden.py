@@ -233,3 +233,26 @@ def test_koleo_loss_golden(golden, tag):
     assert float(l) == pytest.approx(float(g[f"{tag}_loss"]), rel=1e-5 if tag == "small" else 5e-4, abs=1e-6)
     ref = t(g[f"{tag}_dx"])
     assert float((x.grad - ref).norm() / ref.norm()) < (2e-5 if tag == "small" else 1e-3)
+
+
+def test_multicrop_extension_anchors():
+    """The multi-crop extension is not in the reference; its oracle is anchored three ways: the pair-loop loss with
+    no local crops IS the reference-pinned 2-view loss; the bicubic matrix equals torch's own bicubic resize; a model fed
+    native-size input never touches the interpolation."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(3)
+    B, K = 6, 96
+    s, tt_, c = 3 * torch.randn(2 * B, K, generator=g), 1.5 * torch.randn(2 * B, K, generator=g), 0.1 * torch.randn(1, K, generator=g)
+    assert float(O.dino_loss_multicrop(s, tt_, c, 0.1, 0.04)) == pytest.approx(float(O.dino_loss(s, tt_, c, 0.1, 0.04)), rel=1e-6)
+    # 2 global + 3 local views: every (teacher view, other student view) pair, averaged
+    sl = 3 * torch.randn(5 * B, K, generator=g)
+    tp = torch.softmax((tt_ - c) / 0.04, -1).reshape(2, B, K)
+    ls = torch.log_softmax(sl / 0.1, -1).reshape(5, B, K)
+    want = sum(-(tp[q] * ls[v]).sum(-1).mean() for q in range(2) for v in range(5) if v != q) / 8
+    assert float(O.dino_loss_multicrop(sl, tt_, c, 0.1, 0.04)) == pytest.approx(float(want), rel=1e-6)
+    for g_in, g_out in [(14, 6), (4, 2), (7, 7), (4, 9)]:
+        pos = torch.randn(1, 1 + g_in * g_in, 8, generator=g)
+        grid = pos[0, 1:].reshape(g_in, g_in, 8).permute(2, 0, 1)[None]
+        ref = F.interpolate(grid, size=(g_out, g_out), mode="bicubic", align_corners=False)[0].permute(1, 2, 0).reshape(g_out * g_out, 8)
+        got = O.interpolate_pos(pos, g_out)
+        assert torch.equal(got[:, :1], pos[:, :1]) and torch.allclose(got[0, 1:], ref, atol=2e-6), (g_in, g_out)

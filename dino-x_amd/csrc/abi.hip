@@ -40,9 +40,10 @@ extern "C" const char* dinox_last_error(void) { return dinox::g_err; }
 
 extern "C" int dinox_device_ok(void) {
   int n = 0;
-  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+  const hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
     (void)hipGetLastError();
-    dinox::set_error("no HIP device visible");
+    dinox::set_error("no HIP device visible (hipGetDeviceCount: %s, %d devices)", hipGetErrorString(e), n);
     return 0;
   }
   hipDeviceProp_t prop;

@@ -8,6 +8,11 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# PyTorch-ROCm bundles its own libamdhip64; loading it FIRST makes this library's HIP dependency resolve to that same runtime.
+# The other order puts two HIP runtimes in the process, and the second one to initialise finds no device
+# ("no ROCm-capable device is detected"): measured on the MI355X box with `import dinox` ahead of `import torch`.
+import torch  # noqa: F401  (must precede the CDLL below)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DINOX_LIB") or os.path.join(_HERE, "libdinox_hip.so")     # DINOX_LIB: A/B another build of the same ABI
 

@@ -918,3 +918,15 @@ def test_step_multicrop_matches_oracle(dx):
     # without local crops the same engine gives the plain reference step (the extension changes nothing by being there)
     eng2 = TrainEngine(student.to(DEV), teacher.to(DEV), 128, StepHyperParams(lr=1e-3, warmup_steps=1, max_steps=10, ema=0.99))
     assert torch.isfinite(eng2.step(batch.to(DEV), sp2.to(DEV))["loss"])
+
+
+def test_import_order_independent_device_visibility():
+    """`import dinox` ahead of `import torch` must still see the GPU (PyTorch-ROCm bundles its own HIP runtime; the library has
+    to bind to that one, dinox/_lib.py) -- this is the order __graft_entry__.build() followed by smoke() produces."""
+    import subprocess, sys
+    from conftest import PKG, ROOT
+    code = ("import sys; sys.path[:0] = [%r, %r]; import dinox; from dinox import _lib; import torch; "
+            "assert torch.cuda.is_available(); assert _lib.lib.dinox_device_ok() == 1, _lib.last_error(); "
+            "import __graft_entry__ as g; g.build(); print('ok')") % (ROOT, PKG)
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert r.returncode == 0 and b"ok" in r.stdout, r.stdout.decode(errors="replace")[-1500:]

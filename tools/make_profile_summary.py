@@ -66,5 +66,20 @@ md += ["", f"Total kernel time {total_ns / 1e6:.1f} ms over {steps} steps = {tot
 for k, v in list(pmc.items())[:14]:
     md.append(f"| `{k}` | {v['launches']} | {v['fetch_bytes_per_launch_x2_corrected'] / 1e6:.1f} MB | {v['write_bytes_per_launch'] / 1e6:.1f} MB |")
 md.append("")
+sq = sorted(glob.glob(os.path.join(src, "pmc_sq/**/*_counter_collection.csv"), recursive=True))
+mfma_json = os.path.join(prof, f"{tag}_pmc_mfma.json")
+if sq:
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_mfma.py"), sq[-1], mfma_json], check=True, stdout=subprocess.DEVNULL)
+if os.path.exists(mfma_json):
+    mf = json.load(open(mfma_json))
+    md += ["## MFMA-pipe utilisation and wave states (separate SQ counter pass)", "",
+           "`rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -- python bench.py "
+           f"--steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing`; summary by `tools/pmc_mfma.py` in `{tag}_pmc_mfma.json`.  MFMA utilisation = "
+           "SQ_VALU_MFMA_BUSY_CYCLES / (dispatch duration x 2.03 GHz x 1024 SIMDs); wave states are fractions of SQ_WAVE_CYCLES (parked = s_waitcnt / "
+           "barrier, issue-stalled = an instruction is ready but cannot issue, issuing = an instruction issues).", "",
+           "| kernel family | launches | MFMA utilisation | parked | issue-stalled | issuing |", "|---|---|---|---|---|---|"]
+    for k, v in list(mf.items())[:8]:
+        md.append(f"| `{k}` | {v['launches']} | {100 * v['mfma_util']:.1f} % | {v['wave_wait_any']:.2f} | {v['wave_wait_inst']:.2f} | {v['wave_active_inst']:.2f} |")
+    md.append("")
 open(os.path.join(prof, f"{tag}_bench_bs256_summary.md"), "w").write("\n".join(md))
 print("\n".join(md[-20:]))

@@ -15,5 +15,7 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python ben
 echo "[refresh] FETCH_SIZE pass done"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > "$OUT/pmc_write.log" 2>&1
 echo "[refresh] WRITE_SIZE pass done"
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_sq" -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > "$OUT/pmc_sq.log" 2>&1
+echo "[refresh] SQ pass done"
 find "$OUT" -name "*_kernel_trace.csv" -delete        # large; the stats CSV is what gets committed
 find "$OUT" -name "*.db" -delete

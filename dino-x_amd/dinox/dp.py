@@ -26,6 +26,15 @@ import torch
 import torch.distributed as dist
 
 
+def exchanging(group=None) -> bool:
+    """True when collectives have to run: a process group with more than one rank -- or any initialised group when
+    DINOX_DP_FORCE_COLLECTIVES is set, which sends every collective of the step through the backend even at world size 1
+    (how the RCCL call surface is exercised on a one-GPU box: tests/test_gpu_parity.py::test_rccl_call_surface_world1)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or bool(os.environ.get("DINOX_DP_FORCE_COLLECTIVES"))
+
+
 def env_rank_world() -> Tuple[int, int, int]:
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
@@ -33,7 +42,7 @@ def env_rank_world() -> Tuple[int, int, int]:
 def init_process_group(backend: Optional[str] = None) -> Tuple[int, int, int]:
     """Initialise torch.distributed from the torchrun environment (no-op for world size 1)."""
     rank, world, local = env_rank_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("DINOX_DP_FORCE_COLLECTIVES")) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver
@@ -73,6 +82,7 @@ class GradBucketer:
         self.flat = flat_grad
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.exchange = exchanging(group)
         self.buckets: List[_Bucket] = []
         self.bucket_of: Dict[int, int] = {}
         cap = max(1, bucket_bytes // flat_grad.element_size())
@@ -96,7 +106,7 @@ class GradBucketer:
         self._seen: set = set()
         self.active = True          # False on all but the last micro-batch of a gradient-accumulation group
         self._hooks = []
-        if self.world > 1:
+        if self.exchange:
             for i, p in enumerate(params):
                 if p.requires_grad:
                     self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
@@ -118,12 +128,12 @@ class GradBucketer:
         self._seen.add(i)
         b = self.buckets[self.bucket_of[i]]
         b.pending -= 1
-        if b.pending == 0 and self.world > 1 and self.active:
+        if b.pending == 0 and self.exchange and self.active:
             b.work = dist.all_reduce(self.flat[b.lo:b.hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def finish(self) -> None:
         """Launch any bucket that never filled (parameters without gradient) and wait for all."""
-        if self.world <= 1 or not self.active:
+        if not self.exchange or not self.active:
             return
         for b in self.buckets:
             if b.work is None:
@@ -140,7 +150,7 @@ class GradBucketer:
 
 def all_reduce_mean_(t: torch.Tensor, group=None) -> torch.Tensor:
     """In-place mean over ranks (no-op for world size 1)."""
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if exchanging(group):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
         t.div_(dist.get_world_size(group))
     return t

@@ -32,7 +32,7 @@ import torch
 import torch.distributed as dist
 
 from . import ops
-from .dp import GradBucketer, all_reduce_mean_
+from .dp import GradBucketer, all_reduce_mean_, exchanging
 from .schedule import get_lr
 
 
@@ -94,7 +94,7 @@ class TrainEngine:
         self.flat_t, t_params, t_off = flatten_parameters(teacher)
         if t_off != self.offsets or self.flat_t.numel() != self.flat_p.numel():
             raise ValueError("student and teacher must have identical parameter layouts")
-        if self.world > 1:                                   # identical start on every rank
+        if exchanging(process_group):                        # identical start on every rank
             dist.broadcast(self.flat_p, src=0, group=process_group)
             dist.broadcast(self.flat_t, src=0, group=process_group)
         self.flat_g = torch.zeros_like(self.flat_p)
@@ -133,7 +133,7 @@ class TrainEngine:
         self.bucketer.active = last
         self.bucketer.arm()
         if ops.grad_sink.owner is not self:      # weight gradients accumulate straight into flat_g (ops._GradSink)
-            ops.grad_sink.register(self, self.params, self.bucketer.grad_ready if self.world > 1 else None)
+            ops.grad_sink.register(self, self.params, self.bucketer.grad_ready if self.bucketer.exchange else None)
             ops.weight_cache.shadows = self.shadows
         ops.grad_sink.uses.clear()
         with ops.compute_dtype(self.compute_dtype):

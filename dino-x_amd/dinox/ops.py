@@ -957,12 +957,14 @@ class KoLeoFn(torch.autograd.Function):
         x = _c(x.float())
         V, D = x.shape
         dev = x.device
-        world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
-        rank = dist.get_rank(group) if world > 1 else 0
+        from .dp import exchanging
+        gather = exchanging(group)
+        world = dist.get_world_size(group) if gather else 1
+        rank = dist.get_rank(group) if gather else 0
         f = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
         xh, norm, sq = f(V, D), f(V), f(V)
         check(lib.dinox_koleo_normalize(_p(x), _p(xh), _p(norm), _p(sq), V, D, 1e-12, _stream()), "dinox_koleo_normalize")
-        if world > 1:
+        if gather:
             xh_all, sq_all = f(world * V, D), f(world * V)
             dist.all_gather_into_tensor(xh_all, xh, group=group)
             dist.all_gather_into_tensor(sq_all, sq, group=group)
@@ -973,7 +975,7 @@ class KoLeoFn(torch.autograd.Function):
         idx = torch.empty(V, dtype=torch.int32, device=dev)
         dmin = f(V)
         check(lib.dinox_koleo_nn(_p(G), Vg, _p(sq_all), _p(xh_all), row0, V, Vg, D, _p(idx), _p(dmin), _stream()), "dinox_koleo_nn")
-        if world > 1:
+        if gather:
             idx_all = torch.empty(Vg, dtype=torch.int32, device=dev)
             d_all = f(Vg)
             dist.all_gather_into_tensor(idx_all, idx, group=group)

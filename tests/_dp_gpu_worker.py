@@ -27,6 +27,8 @@ teacher.load_state_dict(student.state_dict())
 eng = TrainEngine(student.to(dev), teacher.to(dev), 256, StepHyperParams(lr=1e-3, warmup_steps=1, max_steps=10, ema=0.99, koleo_weight=0.1),
                   bucket_bytes=64 << 10)
 assert world == 1 or len(eng.bucketer.buckets) >= 3
+if os.environ.get("DINOX_DP_FORCE_COLLECTIVES"):
+    assert eng.bucketer.exchange and torch.distributed.get_backend() == os.environ.get("DINOX_EXPECT_BACKEND", torch.distributed.get_backend())
 g = torch.Generator().manual_seed(7)
 B = 8
 v1, v2 = torch.randn(B, 3, 56, 56, generator=g), torch.randn(B, 3, 56, 56, generator=g)
@@ -38,6 +40,6 @@ for _ in range(2):
     eng.step(batch, sp2)
 sc = eng.scalars()
 torch.save({"flat_p": eng.flat_p.cpu(), "center": eng.center.cpu(), "loss": sc["loss"], "grad_norm": sc["grad_norm"]}, sys.argv[1])
-if world > 1:
+if torch.distributed.is_initialized():
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()

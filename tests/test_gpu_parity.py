@@ -930,3 +930,28 @@ def test_import_order_independent_device_visibility():
             "import __graft_entry__ as g; g.build(); print('ok')") % (ROOT, PKG)
     r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     assert r.returncode == 0 and b"ok" in r.stdout, r.stdout.decode(errors="replace")[-1500:]
+
+
+def test_rccl_call_surface_world1(tmp_path):
+    """Every collective of the step (broadcast of the arenas, bucketed async all-reduce launched from backward, centre all-reduce,
+    KoLeo all-gathers, barrier) goes through the real RCCL backend ("nccl") in a world of ONE rank (a one-GPU box cannot hold two
+    RCCL ranks): the result must equal the run without a process group -- a sum over one rank is the identity."""
+    import os, socket, subprocess, sys
+    from conftest import ROOT
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    worker = os.path.join(ROOT, "tests", "_dp_gpu_worker.py")
+    base = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    base.pop("DINOX_DIST_BACKEND", None)
+    outs = {}
+    for tag, extra in (("plain", {}), ("rccl", {"DINOX_DP_FORCE_COLLECTIVES": "1", "DINOX_EXPECT_BACKEND": "nccl"})):
+        out = str(tmp_path / f"{tag}.pt")
+        r = subprocess.run([sys.executable, worker, out], env=dict(base, **extra), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+        assert r.returncode == 0, r.stdout.decode(errors="replace")[-2000:]
+        outs[tag] = torch.load(out)
+    a, b = outs["plain"], outs["rccl"]
+    # not bit for bit: the split-K dW products meet in fp32 atomics, whose order differs from run to run (and Adam turns a
+    # numerically-zero gradient into a +-lr move); two plain runs differ by as much
+    assert a["loss"] == pytest.approx(b["loss"], rel=2e-4) and a["grad_norm"] == pytest.approx(b["grad_norm"], rel=2e-4)
+    assert torch.allclose(a["center"], b["center"], rtol=1e-5, atol=1e-7)
+    d = (a["flat_p"] - b["flat_p"]).abs()
+    assert float((d <= 1e-5).double().mean()) > 0.99 and float(d.max()) <= 2.1e-3

@@ -955,3 +955,44 @@ def test_rccl_call_surface_world1(tmp_path):
     assert torch.allclose(a["center"], b["center"], rtol=1e-5, atol=1e-7)
     d = (a["flat_p"] - b["flat_p"]).abs()
     assert float((d <= 1e-5).double().mean()) > 0.99 and float(d.max()) <= 2.1e-3
+
+
+@pytest.mark.parametrize("name", ["configs0_vit_tiny_cifar", "configs1_vit_small_not_scale_aware"])
+def test_baseline_secondary_configs_step_matches_oracle(dx, name):
+    """BASELINE.json's other configurations as parity cases (one optimiser step, fp32 parity mode, against the oracle):
+    configs[0] = the CIFAR plumbing model (ViT-Tiny dim 192 / depth 12 / heads 3 / out 4096, 32 px, patch 4 -> 64 patches + CLS
+    + 4 registers, no scale embedding, Gram term off as in scripts/baseline_cifar10_pretrain.py);
+    configs[1] = ViT-S/16 at 224 px with scale-aware OFF.  Batches are cut to what the CPU oracle steps in seconds."""
+    ops, arch = dx
+    from dinox.engine import StepHyperParams, TrainEngine
+    from oracle import dinox_oracle as O
+    if name.startswith("configs0"):
+        kw = dict(img_size=32, patch=4, dim=192, depth=12, heads=3, num_registers=4, scale_aware=False)
+        out_dim, B, gram_w = 4096, 4, 0.0
+    else:
+        kw = dict(img_size=224, patch=16, dim=384, depth=12, heads=6, num_registers=4, scale_aware=False)
+        out_dim, B, gram_w = 8192, 2, 1.0
+    cfg = O.VitCfg(out_dim=out_dim, **kw)
+    st = O.init_state(cfg, O.random_params(cfg, seed=21))
+    g = torch.Generator().manual_seed(22)
+    batch = torch.randn(2 * B, 3, kw["img_size"], kw["img_size"], generator=g)
+    st.teacher = {k: v + 0.01 * torch.randn(v.shape, generator=g) for k, v in st.teacher.items()}
+    sd, tsd = {k: v.clone() for k, v in st.student.items()}, {k: v.clone() for k, v in st.teacher.items()}
+    want = O.train_step(st, batch, None, O.HyperParams(lr=1e-3, warmup_steps=1, max_steps=10, ema=0.99, gram_weight=gram_w))
+    student = arch.DinoStudentTeacher(arch.PatchViT(**kw), out_dim)
+    teacher = arch.DinoStudentTeacher(arch.PatchViT(**kw), out_dim)
+    student.load_state_dict(sd)
+    teacher.load_state_dict(tsd)
+    eng = TrainEngine(student.to(DEV), teacher.to(DEV), out_dim,
+                      StepHyperParams(lr=1e-3, warmup_steps=1, max_steps=10, ema=0.99, gram_weight=gram_w))
+    eng.step(batch.to(DEV), None)
+    got = eng.scalars()
+    for k in ("loss", "dino", "grad_norm") + (("gram",) if gram_w else ()):
+        assert got[k] == pytest.approx(want[k], rel=1e-3), (k, got[k], want[k])
+    names = [n for n, _ in student.named_parameters()]
+    worst = 0.0
+    for n, p in zip(names, eng.params):
+        ref = want["grads"][n]
+        if float(ref.abs().max()) > 1e-6:
+            worst = max(worst, rel_l2(p.grad, ref))
+    assert worst < 2e-3, worst

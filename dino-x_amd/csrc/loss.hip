@@ -107,7 +107,36 @@ __global__ __launch_bounds__(256) void final_sum_kernel(const float* __restrict_
   if (threadIdx.x == 0) out[0] = a * scale;
 }
 
+// A workgroup owns 64 float4 column groups; its four 64-thread slices sum interleaved quarters of the rows (4 independent
+// float4 loads in flight per thread) and meet in LDS in a fixed order (deterministic).
 __global__ __launch_bounds__(256) void colmean_kernel(const float* __restrict__ t, float* __restrict__ out, int rows, int K) {
+  __shared__ float4 part[4][64];
+  const int K4 = K / 4, c4 = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c4 < K4) {
+    const float* base = t + c4 * 4;
+    int r = slice;
+    for (; r + 12 < rows; r += 16) {
+      const float4 a = *reinterpret_cast<const float4*>(base + (int64_t)r * K), b = *reinterpret_cast<const float4*>(base + (int64_t)(r + 4) * K);
+      const float4 c = *reinterpret_cast<const float4*>(base + (int64_t)(r + 8) * K), d = *reinterpret_cast<const float4*>(base + (int64_t)(r + 12) * K);
+      s.x += (a.x + b.x) + (c.x + d.x); s.y += (a.y + b.y) + (c.y + d.y); s.z += (a.z + b.z) + (c.z + d.z); s.w += (a.w + b.w) + (c.w + d.w);
+    }
+    for (; r < rows; r += 4) {
+      const float4 a = *reinterpret_cast<const float4*>(base + (int64_t)r * K);
+      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+    }
+  }
+  part[slice][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (slice == 0 && c4 < K4) {
+    const float inv = 1.0f / (float)rows;
+    const float4 p0 = part[0][threadIdx.x], p1 = part[1][threadIdx.x], p2 = part[2][threadIdx.x], p3 = part[3][threadIdx.x];
+    *reinterpret_cast<float4*>(out + c4 * 4) = make_float4(((p0.x + p1.x) + (p2.x + p3.x)) * inv, ((p0.y + p1.y) + (p2.y + p3.y)) * inv,
+                                                           ((p0.z + p1.z) + (p2.z + p3.z)) * inv, ((p0.w + p1.w) + (p2.w + p3.w)) * inv);
+  }
+}
+// any K / alignment
+__global__ __launch_bounds__(256) void colmean_scalar_kernel(const float* __restrict__ t, float* __restrict__ out, int rows, int K) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= K) return;
   float a = 0.f;
@@ -231,7 +260,10 @@ extern "C" int dinox_dino_ce_multi(const float* s, const float* t, const float* 
 
 extern "C" int dinox_colmean(const float* t, float* out, int rows, int K, void* stream) {
   DX_REQUIRE(t && out && rows > 0 && K > 0, DINOX_EINVAL, "colmean: bad arguments");
-  hipLaunchKernelGGL(colmean_kernel, dim3((unsigned)ceil_div(K, 256)), dim3(256), 0, as_stream(stream), t, out, rows, K);
+  if (K % 4 == 0 && (((uintptr_t)t | (uintptr_t)out) & 15) == 0)
+    hipLaunchKernelGGL(colmean_kernel, dim3((unsigned)ceil_div(K / 4, 64)), dim3(256), 0, as_stream(stream), t, out, rows, K);
+  else
+    hipLaunchKernelGGL(colmean_scalar_kernel, dim3((unsigned)ceil_div(K, 256)), dim3(256), 0, as_stream(stream), t, out, rows, K);
   return check_launch("colmean");
 }
 

@@ -130,6 +130,7 @@ class TrainEngine:
         last = (self.step_count + 1) % self.accum == 0
         if first:
             self.flat_g.zero_()
+        ops._UNFOLD_CACHE.clear()    # the unfolded batch is shared by student and teacher WITHIN a step, never carried across steps
         self.bucketer.active = last
         self.bucketer.arm()
         if ops.grad_sink.owner is not self:      # weight gradients accumulate straight into flat_g (ops._GradSink)

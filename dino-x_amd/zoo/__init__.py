@@ -1,7 +1,6 @@
-"""Drop-in ``zoo`` surface of DINO-X, backed by the MI355X HIP engine.
+"""The ``zoo`` package name of timlawrenz/DINO-X, served by the MI355X HIP engine (dinox).
 
-    from zoo.hub import load_model
-    from zoo.encode import encode
-    from zoo.arch import PatchViT, ScaleEmbedding
+Sub-modules mirror the reference's import paths so its call sites keep working: ``zoo.arch`` (model classes), ``zoo.hub``
+(``load_model``), ``zoo.encode`` (``encode``, ``encode_batch``), ``zoo.models`` (catalogue / lineage records).
+Nothing is imported eagerly: importing ``zoo.models`` alone must not load the kernel library.
 """
-from __future__ import annotations

@@ -88,16 +88,17 @@ def collate_stacks(items: Sequence[Tuple[np.ndarray, Sequence[ViewParams], torch
     return StackBatch(raw, offsets, shapes, views, torch.stack([it[2] for it in items], 0))
 
 
-def make_views(batch: StackBatch, size: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def make_views(batch: StackBatch, size: int, out: Optional[torch.Tensor] = None, views: Optional[List[List[ViewParams]]] = None) -> torch.Tensor:
     """(n_views * B, 3, size, size) fp32 on the device of ``batch.raw``, ordered [view 0 of every sample; view 1 ...] like
-    ``torch.cat(views, 0)`` in the reference loop (scripts/phase5_big_run.py:1711)."""
+    ``torch.cat(views, 0)`` in the reference loop (scripts/phase5_big_run.py:1711).  ``views`` selects a subset of
+    ``batch.views`` (e.g. the global views at one size, the local crops of the multi-crop extension at another)."""
     from . import ops
     from ._lib import check, lib
     raw = batch.raw
     ops._need_cuda(raw)
     assert raw.dtype in (torch.int16, torch.uint16) and raw.is_contiguous()
     rows_i, rows_f, max_crop = [], [], 1
-    for vs in batch.views:
+    for vs in (batch.views if views is None else views):
         for i, p in enumerate(vs):
             H, W = batch.shapes[i]
             if not (0 <= p.top and p.top + p.h <= H and 0 <= p.left and p.left + p.w <= W and p.h > 0 and p.w > 0):

@@ -239,6 +239,7 @@ class PngDataset(torch.utils.data.Dataset):
         self.rw_level_min, self.rw_level_max, self.rw_width_min, self.rw_width_max = rw_level_min, rw_level_max, rw_width_min, rw_width_max
         self.crop_scale = (crop_scale_min, crop_scale_max)
         self.raw_views = False          # True: __getitem__ returns (u16 stack, view draws, spacing) for the device-side pipeline
+        self.local_crops, self.local_scale = 0, (0.05, 0.3)      # multi-crop extension: extra student-only views (DINO's local-crop scale)
         self._series_map: dict = {}
         for r in rows:
             self._series_map.setdefault(r.series_dir, {})[r.slice_index] = r.png_path
@@ -275,7 +276,9 @@ class PngDataset(torch.utils.data.Dataset):
                     H, W = stack.shape[1:]
                     kw = dict(rw_level=(self.rw_level_min, self.rw_level_max), rw_width=(self.rw_width_min, self.rw_width_max),
                               crop_scale=self.crop_scale)
-                    return stack, [draw_view(H, W, **kw), draw_view(H, W, **kw)], spacing
+                    views = [draw_view(H, W, **kw), draw_view(H, W, **kw)]
+                    views += [draw_view(H, W, **dict(kw, crop_scale=self.local_scale)) for _ in range(self.local_crops)]
+                    return stack, views, spacing
                 return [self._view(slices), self._view(slices)], spacing
             except Exception as e:
                 print(f"⚠️  Data loading error at index {idx} ({self.rows[idx].png_path}): {e}")
@@ -543,6 +546,10 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--log-json", type=Path, default=None, help="Write one JSON line per training step to this file")
     # extension (not in the reference): data source for environments without a dataset
     ap.add_argument("--synthetic", type=int, default=0, metavar="N", help="Train on N seeded synthetic HU slice stacks instead of --index-csv")
+    ap.add_argument("--local-crops", type=int, default=0, metavar="L",
+                    help="Multi-crop extension (the reference trains on 2 global views): L extra student-only local views per sample, "
+                         "crop scale 0.05-0.3; needs --gpu-views")
+    ap.add_argument("--local-size", type=int, default=96, help="Side of the local views (a multiple of the patch size)")
     ap.add_argument("--gpu-views", action="store_true",
                     help="Build both views on the GPU (HU decode, window, antialiased bicubic RandomResizedCrop, flip, normalise in one "
                          "kernel); DataLoader workers then only decode PNGs")
@@ -675,7 +682,12 @@ def main(argv=None) -> None:
     def _worker_init(worker_id: int) -> None:
         _seed_all(args.train_seed + 1000 * rank + worker_id)
 
+    if args.local_crops and not args.gpu_views:
+        raise SystemExit("--local-crops needs --gpu-views (local crops are produced by the device-side view pipeline)")
+    if args.local_crops and args.local_size % model_cfg.patch:
+        raise SystemExit(f"--local-size {args.local_size} is not a multiple of the patch size {model_cfg.patch}")
     ds.raw_views = bool(args.gpu_views)
+    ds.local_crops = int(args.local_crops)
     if args.gpu_views:
         from dinox.views import collate_stacks, make_views
         say("gpu_views=True")
@@ -729,14 +741,18 @@ def main(argv=None) -> None:
         except StopIteration:
             it = iter(dl)
             item = next(it)
+        loc = spl = None
         if args.gpu_views:
             sb = item.to(device)
-            batch, spacing = make_views(sb, args.img_size), sb.spacing
+            batch, spacing = make_views(sb, args.img_size, views=sb.views[:2]), sb.spacing
+            if args.local_crops:
+                loc = make_views(sb, args.local_size, views=sb.views[2:])
+                spl = torch.cat([spacing] * args.local_crops, 0) if args.scale_aware else None
         else:
             views, spacing = item
             batch = torch.cat(views, 0).to(device, non_blocking=True)
         sp2 = torch.cat([spacing, spacing], 0).to(device, non_blocking=True) if args.scale_aware else None
-        out = eng.step(batch, sp2)
+        out = eng.step(batch, sp2, loc, spl)
         cur = (step, out["loss"], out["lr"])
         # the loss of step s is read back while step s+1 is already queued
         for (s_, loss_t, lr_) in ([pending] if pending is not None else []):

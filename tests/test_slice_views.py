@@ -140,3 +140,18 @@ def test_cli_gpu_views_equals_cpu_views(cli, tmp_path):
     assert [l["step"] for l in logs[0]] == [0, 1, 2, 3] == [l["step"] for l in logs[1]]
     for a, b in zip(*logs):
         assert a["loss"] == pytest.approx(b["loss"], rel=1e-3), (a, b)
+
+
+@pytest.mark.gpu
+def test_cli_multicrop_runs(cli, tmp_path):
+    """--local-crops (extension): 2 global + 2 local views per sample through the device-side pipeline and the multi-crop step."""
+    import json
+    log = tmp_path / "mc.jsonl"
+    cli.main(["--config", "vit-tiny", "--vit-patch", "16", "--vit-dim", "64", "--vit-depth", "2", "--vit-heads", "2", "--out-dim", "256",
+              "--img-size", "32", "--batch-size", "8", "--scale-aware", "--amp", "--synthetic", "32", "--num-workers", "0", "--warmup-steps", "2",
+              "--lr", "1e-3", "--max-steps", "4", "--ckpt-every", "100", "--gpu-views", "--local-crops", "2", "--local-size", "16",
+              "--koleo-weight", "0.1", "--log-json", str(log), "--run-dir", str(tmp_path / "mc")])
+    lines = [json.loads(l) for l in log.read_text().splitlines()]
+    assert [l["step"] for l in lines] == [0, 1, 2, 3] and all(np.isfinite(l["loss"]) for l in lines)
+    with pytest.raises(SystemExit, match="needs --gpu-views"):
+        cli.main(["--config", "vit-tiny", "--synthetic", "16", "--local-crops", "2", "--max-steps", "1", "--run-dir", str(tmp_path / "x")])

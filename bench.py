@@ -38,6 +38,7 @@ import torch                      # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_BF16_DENSE_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16 MFMA
+PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
 def fwd_flops_per_image(img=224, patch=16, dim=384, depth=12, out_dim=8192, regs=4, gram=True):
@@ -178,12 +179,26 @@ def main() -> None:
         if kernels:
             dom = max(kernels, key=lambda k: kernels[k]["ms"])
             d = kernels[dom]
-            ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
-            roof.update(kernel=dom, achieved=round(ach, 2), frac=round(ach / PEAK_BF16_DENSE_TFLOPS, 4),
-                        launches_per_step=d["launches"] // args.steps, avg_launch_us=round(1e3 * d["ms"] / d["launches"], 2),
+            sec = d["ms"] * 1e-3
+            tf, gbs = d["flops"] / sec / 1e12, d["bytes"] / sec / 1e9
+            # Which roof bounds the dominant kernel is decided from its own launches: the time the MFMA pipe needs for their
+            # algorithmic FLOPs at the dense bf16 peak against the time HBM needs for their algorithmic bytes at its peak.
+            # With K = 384..1536 and M ~ 1e5 the products of this path sit at or under the ridge (2.5 PF / 8 TB/s = 312 FLOP/B;
+            # qkv 288, fc1 with its GELU' side tensor 171, proj 77): the larger floor is the HBM one.
+            t_mfma, t_hbm = d["flops"] / (PEAK_BF16_DENSE_TFLOPS * 1e12), d["bytes"] / (PEAK_HBM_GBS * 1e9)
+            mfma = {"achieved": round(tf, 2), "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_DENSE_TFLOPS, 4),
+                    "floor_ms_per_step": round(1e3 * t_mfma / args.steps, 3)}
+            hbm = {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                   "floor_ms_per_step": round(1e3 * t_hbm / args.steps, 3), "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"])}
+            if t_hbm >= t_mfma:
+                roof.update(bound="hbm", achieved=hbm["achieved"], peak=PEAK_HBM_GBS, unit="GB/s", frac=hbm["frac"], mfma=mfma, hbm=hbm)
+            else:
+                roof.update(bound="mfma", achieved=mfma["achieved"], frac=mfma["frac"], mfma=mfma, hbm=hbm)
+            roof.update(kernel=dom, launches_per_step=d["launches"] // args.steps, avg_launch_us=round(1e3 * d["ms"] / d["launches"], 2),
                         kernel_share_of_step=round(d["ms"] / (dt * 1e3), 4),
                         all_gemm_kernels={k: {"launches": v["launches"], "ms": round(v["ms"], 3),
-                                              "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in kernels.items()})
+                                              "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                                              "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)} for k, v in kernels.items()})
         # HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE and, in a
         # separate run, WRITE_SIZE of this same command; FETCH doubled per the gfx950 correction) -- bench.py cannot
         # run the profiler on itself, so the figure is read from profiles/ and is null when that file is absent.
@@ -192,7 +207,7 @@ def main() -> None:
             fam = "dinox::" + roof.get("kernel", "")
             if fam in pmc and args.model == "vit-small" and B == 256 and not L:
                 roof["traffic"] = pmc[fam]["hbm_bytes_per_launch"]
-                roof["traffic_note"] = "avg HBM bytes/launch, profiles/r01_pmc_traffic.json; algorithmic avg ~447e6 (operands+outputs once)"
+                roof["traffic_note"] = "measured avg HBM bytes/launch (PMC, profiles/r01_pmc_traffic.json) beside hbm.algorithmic_bytes_per_launch"
         except (OSError, ValueError, KeyError):
             pass
         roof["step"] = {"gflop_per_sample": round(gf_sample, 2), "achieved": round(step_tflops, 2),

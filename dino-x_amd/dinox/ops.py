@@ -91,21 +91,40 @@ class GemmTimer:
     def _event(self):
         return self.pool.pop() if self.pool else torch.cuda.Event(enable_timing=True)
 
+    @staticmethod
+    def algorithmic_bytes(g) -> float:
+        """HBM bytes one launch has to move if every operand and result crosses the memory interface exactly once:
+        A (M x K) and B (N x K, once if shared by the batch) in the input dtype, C (M x N) in the output dtype, plus the
+        epilogue's extra tensors -- the fp32 residual read, the GELU' side tensor written (GELU) or read (DGELU), C read back
+        under ACCUM."""
+        isz = 2 if g.in_dtype == BF16 else 4
+        osz = 2 if g.out_dtype == BF16 else 4
+        mn = float(g.M) * g.N * g.batch
+        b = float(g.M) * g.K * g.batch * isz + float(g.N) * g.K * isz * (g.batch if g.strideB else 1) + mn * osz
+        if g.epilogue & EPI_RESIDUAL:
+            b += mn * 4
+        if g.aux and (g.epilogue & (EPI_GELU | EPI_DGELU)):
+            b += mn * osz
+        if g.epilogue & EPI_ACCUM:
+            b += mn * 4
+        return b
+
     def launch(self, g, stream) -> None:
         name = lib.dinox_gemm_kernel_name(C.byref(g)).decode()
         e0, e1 = self._event(), self._event()
         e0.record()
         check(lib.dinox_gemm(C.byref(g), stream), "dinox_gemm")
         e1.record()
-        self.records.append((name, 2.0 * g.M * g.N * g.K * g.batch, e0, e1))
+        self.records.append((name, 2.0 * g.M * g.N * g.K * g.batch, self.algorithmic_bytes(g), e0, e1))
 
     def summary(self) -> dict:
-        """{kernel: {"launches", "flops", "ms"}} -- call after a device synchronise."""
+        """{kernel: {"launches", "flops", "bytes", "ms"}} -- call after a device synchronise."""
         out: dict = {}
-        for name, fl, e0, e1 in self.records:
-            d = out.setdefault(name, {"launches": 0, "flops": 0.0, "ms": 0.0})
+        for name, fl, by, e0, e1 in self.records:
+            d = out.setdefault(name, {"launches": 0, "flops": 0.0, "bytes": 0.0, "ms": 0.0})
             d["launches"] += 1
             d["flops"] += fl
+            d["bytes"] += by
             d["ms"] += e0.elapsed_time(e1)
             self.pool += [e0, e1]
         self.records = []

@@ -43,6 +43,8 @@ SIGNATURES = {
     "dinox_gemm": (i32, [C.POINTER(GemmArgs), vp]),
     "dinox_gemm_kernel_name": (C.c_char_p, [C.POINTER(GemmArgs)]),
     "dinox_colsum": (i32, [vp, vp, i64, i64, i64, i32, i32, vp]),
+    "dinox_mlp_fwd_fused_ok": (i32, [i32, i32]),
+    "dinox_mlp_fwd_fused": (i32, [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
     "dinox_layernorm_fwd": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, f32, i32, vp]),
     "dinox_layernorm_bwd_ws_bytes": (i64, [i64, i32]),
     "dinox_layernorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]),

@@ -14,6 +14,7 @@ from __future__ import annotations
 import contextlib
 import ctypes as C
 import math
+import os
 from typing import Optional
 
 import torch
@@ -323,6 +324,26 @@ def weight_operand(w: Tensor, dt: torch.dtype, transposed=False) -> Tensor:
     return weight_cache.get(w, transposed)
 
 
+def mlp_fused_ok(D: int, H: int) -> bool:
+    """Opt-in (DINOX_FUSED_MLP=1): at ViT-S sizes the fused kernel measures 534 us against 438 us for the two GEMMs it replaces
+    (one wave per SIMD exposes every per-chunk latency), so the two-GEMM path stays the default."""
+    return bool(os.environ.get("DINOX_FUSED_MLP")) and bool(lib.dinox_mlp_fwd_fused_ok(D, H))
+
+
+def mlp_fwd_fused(xn: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, residual: Tensor) -> Tensor:
+    """residual + b2 + GELU(xn W1^T + b1) W2^T in one kernel (bf16 operands, fp32 out); for passes without a backward."""
+    _need_cuda(xn, w1, w2, residual)
+    assert xn.dtype == torch.bfloat16 and w1.dtype == torch.bfloat16 and w2.dtype == torch.bfloat16
+    xn, w1, w2, residual = _c(xn), _c(w1), _c(w2), _c(residual)
+    M, D = xn.shape
+    H = w1.shape[0]
+    assert w1.shape == (H, D) and w2.shape == (D, H) and residual.shape == (M, D) and residual.dtype == torch.float32
+    out = torch.empty((M, D), dtype=torch.float32, device=xn.device)
+    check(lib.dinox_mlp_fwd_fused(_p(xn), _p(w1), _p(_c(b1)), _p(w2), _p(_c(b2)), _p(residual), _p(out), M, D, H, _stream()),
+          "dinox_mlp_fwd_fused")
+    return out
+
+
 def layernorm_fwd(x: Tensor, w: Tensor, b: Tensor, out_dtype: torch.dtype, eps: float = 1e-5):
     _need_cuda(x, w, b)
     assert x.dtype == torch.float32
@@ -532,6 +553,10 @@ class BlockFn(torch.autograd.Function):
         o, lse = attention_fwd(qkv.view(V, N, 3 * D), heads)
         x1 = gemm(o.view(M, D), weight_operand(wproj, dt), bias=bproj, residual=x0.view(M, D), out_dtype=torch.float32)
         xn2, mean2, rstd2 = layernorm_fwd(x1, n2w, n2b, dt, eps)
+        if (not train and dt == torch.bfloat16 and b1 is not None and b2 is not None and mlp_fused_ok(D, w1.shape[0])):
+            # nothing is saved for a backward (EMA teacher, inference): the hidden activation stays on chip
+            x2 = mlp_fwd_fused(xn2, weight_operand(w1, dt), b1, weight_operand(w2, dt), b2, x1)
+            return x2.view(V, N, D)
         pre = torch.empty((M, w1.shape[0]), dtype=dt, device=x0.device) if train else None
         act = gemm(xn2, weight_operand(w1, dt), bias=b1, gelu=True, aux=pre, auxgrad=True, out_dtype=dt)   # pre := gelu'(fc1 out)
         x2 = gemm(act, weight_operand(w2, dt), bias=b2, residual=x1, out_dtype=torch.float32)

@@ -106,6 +106,17 @@ int dinox_colsum(const void* x, float* out, int64_t M, int64_t N, int64_t ldx, i
                  void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Fused MLP for passes without a backward (EMA teacher, inference) -- replaces Mlp.forward plus the block's
+ * skip connection (zoo/arch.py:75-76, :96) in ONE kernel:  out = residual + b2 + GELU_erf(xn W1^T + b1) W2^T.
+ * xn [M][D] bf16 (LayerNorm output), w1 [H][D] bf16, w2 [D][H] bf16, biases fp32, residual / out [M][D] fp32
+ * (out may alias residual).  The hidden activation [M][H] never reaches HBM.  Envelope: dinox_mlp_fwd_fused_ok(D, H)
+ * (D in {64,128,192,256,384}, H % 32 == 0); everything 16-byte aligned.
+ * ------------------------------------------------------------------------------------------ */
+int dinox_mlp_fwd_fused_ok(int D, int H);
+int dinox_mlp_fwd_fused(const void* xn, const void* w1, const float* b1, const void* w2, const float* b2,
+                        const float* residual, float* out, int64_t M, int D, int H, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * LayerNorm -- replaces nn.LayerNorm(D), eps 1e-5, affine (zoo/arch.py:89,91,126,187; calls :95,96,237).
  * x is the fp32 residual stream; y is written in out_dtype (bf16 when it only feeds a GEMM).
  * bwd: dx = (dx_add ? dx_add : 0) + LN'(dy)  -- dx_add is the gradient arriving over the skip connection of the

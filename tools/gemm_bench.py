@@ -40,6 +40,7 @@ dbd = torch.empty(D, device=dev)
 case("dW2   TN M384 N1536  (+db)       ", lambda: ops.gemm(x, xh, transA=True, transB=True, out_dtype=torch.float32, colsum_out=dbd), 2 * M * D * H, M * H * 2 + M * D * 2)
 case("dWp   TN M384 N384   (+db)       ", lambda: ops.gemm(x, x, transA=True, transB=True, out_dtype=torch.float32, colsum_out=dbd), 2 * M * D * D, 2 * M * D * 2)
 
+case("mlpT  fused fc1+gelu+fc2+res     ", lambda: ops.mlp_fwd_fused(x, w1, bh, w2, bd, res), 4 * M * D * H, M * D * 2 + 2 * M * D * 4)
 if os.environ.get("SQUARE"):
     S = int(os.environ["SQUARE"])
     sa, sb = rb(S, S), rb(S, S)

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(SE_THREADS) void scale_embed_fwd_kernel(
 __global__ __launch_bounds__(SE_THREADS) void scale_embed_bwd_rows(
     const float* __restrict__ dout, const float* __restrict__ w0, const float* __restrict__ w2, const float* __restrict__ lnw,
     const float* __restrict__ hpre, const float* __restrict__ e, const float* __restrict__ mean, const float* __restrict__ rstd,
-    float* __restrict__ de, float* __restrict__ dhpre, float* __restrict__ dspacing, int h, int D) {
+    float* __restrict__ de, float* __restrict__ dhpre, float* __restrict__ hact, float* __restrict__ dspacing, int h, int D) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // de_row[D] | dh[h] | red[16]
   float* der = lds;
   float* dh = lds + D;
@@ -76,9 +76,11 @@ __global__ __launch_bounds__(SE_THREADS) void scale_embed_bwd_rows(
   for (int j = t; j < h; j += SE_THREADS) {
     float s = 0.f;
     for (int dd = 0; dd < D; ++dd) s += der[dd] * w2[(int64_t)dd * h + j];
-    const float d = s * gelu_erf_grad(hpre[(int64_t)v * h + j]);
+    const float hp = hpre[(int64_t)v * h + j];
+    const float d = s * gelu_erf_grad(hp);
     dh[j] = d;
     dhpre[(int64_t)v * h + j] = d;
+    hact[(int64_t)v * h + j] = gelu_erf(hp);            // once per element here, not V times per weight in the parameter kernel
   }
   __syncthreads();
   if (dspacing && t < 3) {
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(SE_THREADS) void scale_embed_bwd_rows(
 // parameter gradients: one thread per parameter element, loop over the V rows.
 // index space: [0, D*h) dw2 | +D db2 | +3h dw0 | +h db0 | +D dlnw | +D dlnb
 __global__ __launch_bounds__(256) void scale_embed_bwd_params(
-    const float* __restrict__ dout, const float* __restrict__ sp, const float* __restrict__ hpre, const float* __restrict__ e,
+    const float* __restrict__ dout, const float* __restrict__ sp, const float* __restrict__ hact, const float* __restrict__ e,
     const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ de, const float* __restrict__ dhpre,
     float* __restrict__ dw0, float* __restrict__ db0, float* __restrict__ dw2, float* __restrict__ db2, float* __restrict__ dlnw,
     float* __restrict__ dlnb, int V, int h, int D) {
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(256) void scale_embed_bwd_params(
   float s = 0.f;
   if (idx < n_dw2) {
     const int dd = (int)(idx / h), j = (int)(idx % h);
-    for (int v = 0; v < V; ++v) s += de[(int64_t)v * D + dd] * gelu_erf(hpre[(int64_t)v * h + j]);
+    for (int v = 0; v < V; ++v) s += de[(int64_t)v * D + dd] * hact[(int64_t)v * h + j];
     dw2[idx] = s;
     return;
   }
@@ -152,7 +154,7 @@ extern "C" int dinox_scale_embed_fwd(const float* spacing, const float* w0, cons
 
 extern "C" int64_t dinox_scale_embed_bwd_ws_bytes(int V, int h, int D) {
   if (V <= 0 || h <= 0 || D <= 0) return 0;
-  return (int64_t)V * (D + h) * (int64_t)sizeof(float);
+  return (int64_t)V * (D + 2 * h) * (int64_t)sizeof(float);       // de [V][D] | dhpre [V][h] | gelu(hpre) [V][h]
 }
 
 extern "C" int dinox_scale_embed_bwd(const float* dout, const float* spacing, const float* w0, const float* w2,
@@ -165,12 +167,13 @@ extern "C" int dinox_scale_embed_bwd(const float* dout, const float* spacing, co
   hipStream_t st = as_stream(stream);
   float* de = (float*)ws;
   float* dhp = de + (int64_t)V * D;
+  float* hact = dhp + (int64_t)V * h;
   hipLaunchKernelGGL(scale_embed_bwd_rows, dim3(V), dim3(SE_THREADS), (size_t)(D + h + 16) * sizeof(float), st, dout, w0, w2,
-                     lnw, hpre, e, mean, rstd, de, dhp, dspacing, h, D);
+                     lnw, hpre, e, mean, rstd, de, dhp, hact, dspacing, h, D);
   int rc = check_launch("scale_embed_bwd_rows");
   if (rc) return rc;
   const int64_t total = (int64_t)D * h + D + 3 * h + h + D + D;
-  hipLaunchKernelGGL(scale_embed_bwd_params, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, dout, spacing, hpre, e,
+  hipLaunchKernelGGL(scale_embed_bwd_params, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, dout, spacing, hact, e,
                      mean, rstd, de, dhp, dw0, db0, dw2, db2, dlnw, dlnb, V, h, D);
   return check_launch("scale_embed_bwd_params");
 }

@@ -1020,3 +1020,40 @@ def test_mlp_fused_matches_two_gemms(dx, M, D, H):
     h = torch.nn.functional.gelu(xn.double() @ w1.double().t() + b1.double()).bfloat16().double()
     ref = res.double() + b2.double() + h @ w2.double().t()
     assert rel_l2(got, ref) < 2e-3
+
+
+def test_vit_large_16_step_matches_oracle(dx):
+    """BASELINE configs[4]'s model (ViT-L/16: dim 1024, 24 blocks, 16 heads, hidden 4096, 201 tokens, scale-aware, Gram on) for
+    one optimiser step at the smallest batch (1 sample = 2 views) against the CPU oracle, fp32 parity mode: loss terms, grad-norm
+    and every parameter gradient.  Exercises the K = 1024 / 4096 GEMM shapes, 16-head attention and the 1024-wide LayerNorm."""
+    ops, arch = dx
+    from dinox.engine import StepHyperParams, TrainEngine
+    from oracle import dinox_oracle as O
+    kw = dict(img_size=224, patch=16, dim=1024, depth=24, heads=16, num_registers=4, scale_aware=True)
+    cfg = O.VitCfg(out_dim=8192, **kw)
+    st = O.init_state(cfg, O.random_params(cfg, seed=31))
+    g = torch.Generator().manual_seed(32)
+    batch = torch.randn(2, 3, 224, 224, generator=g)
+    sp = torch.rand(1, 3, generator=g) * 2 + 0.4
+    sp2 = torch.cat([sp, sp], 0)
+    st.teacher = {k: v + 0.01 * torch.randn(v.shape, generator=g) for k, v in st.teacher.items()}
+    sd, tsd = {k: v.clone() for k, v in st.student.items()}, {k: v.clone() for k, v in st.teacher.items()}
+    want = O.train_step(st, batch, sp2, O.HyperParams(lr=1e-3, warmup_steps=1, max_steps=10, ema=0.99))
+    del st
+    student = arch.DinoStudentTeacher(arch.PatchViT(**kw), 8192)
+    teacher = arch.DinoStudentTeacher(arch.PatchViT(**kw), 8192)
+    student.load_state_dict(sd)
+    teacher.load_state_dict(tsd)
+    del sd, tsd
+    eng = TrainEngine(student.to(DEV), teacher.to(DEV), 8192, StepHyperParams(lr=1e-3, warmup_steps=1, max_steps=10, ema=0.99))
+    eng.step(batch.to(DEV), sp2.to(DEV))
+    got = eng.scalars()
+    for k in ("loss", "dino", "gram", "grad_norm"):
+        assert got[k] == pytest.approx(want[k], rel=1e-3), (k, got[k], want[k])
+    names = [n for n, _ in student.named_parameters()]
+    worst = 0.0
+    for n, p in zip(names, eng.params):
+        ref = want["grads"][n]
+        if float(ref.abs().max()) > 1e-6:
+            worst = max(worst, rel_l2(p.grad, ref))
+    assert worst < 2e-3, worst

@@ -32,7 +32,7 @@ import torch
 import torch.distributed as dist
 
 from . import ops
-from .dp import GradBucketer, all_reduce_mean_, exchanging
+from .dp import GradBucketer, exchanging
 from .schedule import get_lr
 
 
@@ -165,8 +165,9 @@ class TrainEngine:
                 s_out = s_all[:s_feats.shape[0]]
                 l_dino = ops.DinoCEMultiFn.apply(s_all, t_out, self.center, hp.student_temp, hp.teacher_temp, 2)
             # centre EMA after the loss used the old centre; batch mean is global under DP
-            bm = all_reduce_mean_(ops.colmean(t_out), self.group)
-            ops.center_ema_(self.center.view(-1), bm, hp.center_momentum)
+            bm = ops.colmean(t_out)
+            bm_work = dist.all_reduce(bm, op=dist.ReduceOp.SUM, group=self.group, async_op=True) if exchanging(self.group) else None
+            # (the centre itself moves after backward: the loss used the old centre, so the exchange can run under the backward pass)
             if hp.gram_weight != 0.0:
                 l_gram = ops.GramLossFn.apply(s_feats, t_feats)
                 loss = l_dino + hp.gram_weight * l_gram
@@ -179,6 +180,10 @@ class TrainEngine:
             else:
                 l_koleo = torch.zeros((), device=batch.device)
             (loss if self.accum == 1 else loss / self.accum).backward()
+        if bm_work is not None:
+            bm_work.wait()
+            bm.div_(self.world)
+        ops.center_ema_(self.center.view(-1), bm, hp.center_momentum)
         self.bucketer.finish()
         if last:
             self.opt_steps += 1

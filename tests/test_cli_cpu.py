@@ -1,16 +1,13 @@
 """CPU checks of the scripts/phase5_big_run.py drop-in: flag surface, config dataclasses, importable names, host data
 pipeline, checkpoint payload (reference keys; optimiser state in torch.optim.AdamW format).  The flag list below is the
 reference's argparse surface (scripts/phase5_big_run.py:1238-1331) written out as data."""
-import importlib.util
 import json
-import os
 from dataclasses import asdict, fields
 
 import numpy as np
 import pytest
 import torch
 
-from conftest import PKG
 
 REFERENCE_FLAGS = [
     "--config", "--vit-patch", "--vit-dim", "--vit-depth", "--vit-heads", "--out-dim", "--device", "--num-workers", "--pin-memory",

@@ -1,6 +1,5 @@
 """Pin the CPU oracle (oracle/dinox_oracle.py) to fixtures captured from the real reference
 (tests/golden/make_golden.py) and to the known-answer values of SURVEY.md section 8c."""
-import math
 
 import numpy as np
 import pytest

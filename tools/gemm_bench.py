@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Micro-benchmark of dinox_gemm on the hot-path shapes (ViT-S/16 bs256: M = 102912 tokens).
 Interleaved rounds in one process, HIP-event timing, random data (cdna_hip_programming.md rules 24/25)."""
-import os, sys, json
+import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "dino-x_amd")]
 import torch

@@ -90,7 +90,10 @@ def test_gemm_bf16_vs_exact(dx, tA, tB, M, N, K):
     out = ops.gemm(A.to(DEV), B.to(DEV), transA=bool(tA), transB=bool(tB), out_dtype=torch.float32)
     used, ops.TRACE_KERNELS = ops.TRACE_KERNELS, None
     # the MFMA-bf16 kernels must take every aligned NT / TN shape; only (0,1) falls to the fp32-MFMA kernel
-    want = {(0, 0): "gemm_bf16_nt_glds" if (K % 64 == 0 and N % 8 == 0) else "gemm_bf16_nt", (1, 1): "gemm_bf16_tn_dma", (0, 1): "gemm_f32"}[(tA, tB)]
+    nt = "gemm_bf16_nt"
+    if K % 64 == 0 and N % 8 == 0:
+        nt = "gemm_bf16_nt_areg" if K == 384 else "gemm_bf16_nt_glds"      # K = 384: token operand through the register file
+    want = {(0, 0): nt, (1, 1): "gemm_bf16_tn_dma", (0, 1): "gemm_f32"}[(tA, tB)]
     assert used == [want], used
     close(out, ref, rtol=1e-5, atol=1e-5 * math.sqrt(K), what=f"bf16 gemm {tA}{tB} {M}x{N}x{K}")
     out_b = ops.gemm(A.to(DEV), B.to(DEV), transA=bool(tA), transB=bool(tB))
@@ -1057,3 +1060,48 @@ def test_vit_large_16_step_matches_oracle(dx):
         if float(ref.abs().max()) > 1e-6:
             worst = max(worst, rel_l2(p.grad, ref))
     assert worst < 2e-3, worst
+
+
+@pytest.mark.parametrize("M,N", [(1000, 1152), (77, 40), (128 * 9 + 5, 1536), (4096, 384)])
+def test_gemm_nt_areg(dx, M, N):
+    """The K = 384 form of the NT product (token operand prefetched through the register file, csrc/gemm_bf16_areg.hip): plain,
+    bias, GELU with its GELU' side tensor, bf16 and fp32 outputs, ragged M and N, against fp64 on the same bf16 operands."""
+    ops, _ = dx
+    g = torch.Generator().manual_seed(M + N)
+    K = 384
+    A, B = (torch.randn(M, K, generator=g) * 0.5).bfloat16(), (torch.randn(N, K, generator=g) * 0.5).bfloat16()
+    bias = torch.randn(N, generator=g)
+    ref = A.double() @ B.double().t()
+    ops.TRACE_KERNELS = []
+    try:
+        c = ops.gemm(A.to(DEV), B.to(DEV), out_dtype=torch.float32)
+        cb = ops.gemm(A.to(DEV), B.to(DEV), bias=bias.to(DEV))
+        aux = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        act = ops.gemm(A.to(DEV), B.to(DEV), bias=bias.to(DEV), gelu=True, aux=aux, auxgrad=True)
+        assert ops.TRACE_KERNELS == ["gemm_bf16_nt_areg"] * 3, ops.TRACE_KERNELS
+    finally:
+        ops.TRACE_KERNELS = None
+    close(c, ref, 1e-5, 1e-4, "plain fp32 out")
+    assert rel_l2(cb.float(), ref + bias.double()) < 3e-3
+    pre = ref + bias.double()
+    gel = 0.5 * pre * (1 + torch.erf(pre / math.sqrt(2)))
+    dg = 0.5 * (1 + torch.erf(pre / math.sqrt(2))) + pre * torch.exp(-0.5 * pre * pre) / math.sqrt(2 * math.pi)
+    assert rel_l2(act.float(), gel) < 3e-3 and rel_l2(aux.float(), dg) < 3e-3
+
+
+def test_gemm_nt_areg_full_size_repeatable(dx):
+    """BASELINE size (M = 512 views x 201 tokens, qkv product) through the register-prefetch NT kernel, 40 launches back to back:
+    the kernel has no atomics, so every launch must reproduce the first bit for bit (a missed wait on a staged slice shows up as a
+    sporadic difference), and sampled rows must match fp64."""
+    ops, _ = dx
+    g = torch.Generator(device=DEV).manual_seed(0)
+    M, N, K = 512 * 201, 1152, 384
+    A = (torch.randn(M, K, device=DEV, generator=g) * 0.5).bfloat16()
+    B = (torch.randn(N, K, device=DEV, generator=g) * 0.5).bfloat16()
+    bias = torch.randn(N, device=DEV, generator=g)
+    first = ops.gemm(A, B, bias=bias)
+    for _ in range(40):
+        assert torch.equal(ops.gemm(A, B, bias=bias), first)
+    rows = torch.randint(0, M, (256,), device=DEV, generator=g)
+    ref = A[rows].double() @ B.double().t() + bias.double()
+    assert rel_l2(first[rows].float(), ref) < 3e-3

@@ -925,12 +925,12 @@ def test_step_multicrop_matches_oracle(dx):
 
 def test_import_order_independent_device_visibility():
     """`import dinox` ahead of `import torch` must still see the GPU (PyTorch-ROCm bundles its own HIP runtime; the library has
-    to bind to that one, dinox/_lib.py) -- this is the order __graft_entry__.build() followed by smoke() produces."""
+    to bind to that one, dinox/_lib.py) -- this is the order __graft_entry__.build() followed by smoke() produces.  (The test does not
+    run build() itself: compiling is not what it checks.)"""
     import subprocess, sys
     from conftest import PKG, ROOT
     code = ("import sys; sys.path[:0] = [%r, %r]; import dinox; from dinox import _lib; import torch; "
-            "assert torch.cuda.is_available(); assert _lib.lib.dinox_device_ok() == 1, _lib.last_error(); "
-            "import __graft_entry__ as g; g.build(); print('ok')") % (ROOT, PKG)
+            "assert torch.cuda.is_available(); assert _lib.lib.dinox_device_ok() == 1, _lib.last_error(); print('ok')") % (ROOT, PKG)
     r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     assert r.returncode == 0 and b"ok" in r.stdout, r.stdout.decode(errors="replace")[-1500:]
 

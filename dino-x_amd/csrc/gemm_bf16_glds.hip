@@ -192,6 +192,10 @@ __global__ __launch_bounds__(256, (GG_BM == 256 ? 2 : (GG_BK == 64 ? 2 : 3))) vo
       compute(buf);
       buf = buf == 2 ? 0 : buf + 1;
     }
+    // The last step's LDS reads must have returned before this wave reports in (the compiler may leave them in flight across the
+    // barrier, their MFMAs after it): park writes of another wave into the same slot could overtake them.  The park area is slots
+    // 0-1; the last step reads slot (nk - 1) % 3, so this bites when nk % 3 != 0 (K = 1024, 4096: ViT-L), not on ViT-S / ViT-B.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();     // all waves done with the ring before it becomes the park area
   }
 

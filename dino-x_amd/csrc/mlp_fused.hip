@@ -232,6 +232,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_fwd_bf16(const bf16_t* __res
       for (int i = 0; i < 32; ++i) bnext[i] = bb[i];
     }
   }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // (reads still in flight across the barrier could be overtaken by park writes)
   __builtin_amdgcn_s_barrier();                                 // every wave is done with the ring: it becomes the park area
 
   // ---- epilogue: up to 4 output tiles (128 columns) per pass parked per wave (32 rows x 512 B, 16-B chunks XOR (row & 31)),

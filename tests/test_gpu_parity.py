@@ -1062,7 +1062,7 @@ def test_vit_large_16_step_matches_oracle(dx):
     assert worst < 2e-3, worst
 
 
-@pytest.mark.parametrize("M,N", [(1000, 1152), (77, 40), (128 * 9 + 5, 1536), (4096, 384)])
+@pytest.mark.parametrize("M,N", [(1000, 1152), (77, 40), (128 * 9 + 5, 1536), (4096, 384), (128 * 70 + 9, 1152), (128 * 200, 1536)])
 def test_gemm_nt_areg(dx, M, N):
     """The K = 384 form of the NT product (token operand prefetched through the register file, csrc/gemm_bf16_areg.hip): plain,
     bias, GELU with its GELU' side tensor, bf16 and fp32 outputs, ragged M and N, against fp64 on the same bf16 operands."""
@@ -1089,19 +1089,48 @@ def test_gemm_nt_areg(dx, M, N):
     assert rel_l2(act.float(), gel) < 3e-3 and rel_l2(aux.float(), dg) < 3e-3
 
 
-def test_gemm_nt_areg_full_size_repeatable(dx):
+@pytest.mark.parametrize("workers", [0, 768])
+def test_gemm_nt_areg_full_size_repeatable(dx, workers, monkeypatch):
     """BASELINE size (M = 512 views x 201 tokens, qkv product) through the register-prefetch NT kernel, 40 launches back to back:
     the kernel has no atomics, so every launch must reproduce the first bit for bit (a missed wait on a staged slice shows up as a
-    sporadic difference), and sampled rows must match fp64."""
+    sporadic difference), and sampled rows must match fp64.  ``workers`` = 0: one workgroup per tile (the default); 768: the
+    persistent form with cross-tile prefetch (DINOX_NT_AREG_WORKERS).  This test is what caught LDS reads left in flight across
+    the barrier in front of the accumulator parking (one tile in ~1e5 multiplied by parked fp32 words)."""
     ops, _ = dx
+    monkeypatch.setenv("DINOX_NT_AREG_WORKERS", str(workers))
     g = torch.Generator(device=DEV).manual_seed(0)
     M, N, K = 512 * 201, 1152, 384
     A = (torch.randn(M, K, device=DEV, generator=g) * 0.5).bfloat16()
     B = (torch.randn(N, K, device=DEV, generator=g) * 0.5).bfloat16()
     bias = torch.randn(N, device=DEV, generator=g)
     first = ops.gemm(A, B, bias=bias)
-    for _ in range(40):
+    for _ in range(120):
         assert torch.equal(ops.gemm(A, B, bias=bias), first)
+    assert bool(torch.isfinite(first.float()).all())
     rows = torch.randint(0, M, (256,), device=DEV, generator=g)
     ref = A[rows].double() @ B.double().t() + bias.double()
     assert rel_l2(first[rows].float(), ref) < 3e-3
+
+
+@pytest.mark.parametrize("K,N", [(1024, 1024), (1536, 384), (4096, 1024)])
+def test_gemm_nt_glds_repeatable(dx, K, N):
+    """The LDS-DMA ring NT kernel at long K, 60 launches back to back, bit for bit.  K = 1024 and 4096 (ViT-L widths) end the K loop
+    on ring slot 1, which is also where two waves park their accumulators: the last step's LDS reads must have returned before the
+    barrier in front of the parking (csrc/gemm_bf16_glds.hip)."""
+    ops, _ = dx
+    g = torch.Generator(device=DEV).manual_seed(K + N)
+    M = 128 * 400
+    A = (torch.randn(M, K, device=DEV, generator=g) * 0.5).bfloat16()
+    B = (torch.randn(N, K, device=DEV, generator=g) * 0.5).bfloat16()
+    res = torch.randn(M, N, device=DEV, generator=g)
+    ops.TRACE_KERNELS = []
+    try:
+        first = ops.gemm(A, B, residual=res, out_dtype=torch.float32)
+        assert ops.TRACE_KERNELS == ["gemm_bf16_nt_glds"], ops.TRACE_KERNELS
+    finally:
+        ops.TRACE_KERNELS = None
+    for _ in range(60):
+        assert torch.equal(ops.gemm(A, B, residual=res, out_dtype=torch.float32), first)
+    rows = torch.randint(0, M, (128,), device=DEV, generator=g)
+    ref = A[rows].double() @ B.double().t() + res[rows].double()
+    assert rel_l2(first[rows], ref) < 3e-3

@@ -441,10 +441,15 @@ const char* gemm_bf16_variant(const GemmParams& p) {
   if (p.in_dtype != DINOX_BF16) return nullptr;
   if (!aligned16(p.A) || !aligned16(p.B) || (p.lda & 7) || (p.ldb & 7) || (p.strideA & 7) || (p.strideB & 7)) return nullptr;
   if (gemm_bf16_nt_glds_ok(p)) {
-    // K = 384 products without a residual / GELU' epilogue take the form that prefetches the token operand through registers
-    // (+3-5 % on qkv / fc1, +1.4 % on the training step); DINOX_NT_NO_AREG=1 switches it off for A/B runs
+    // Short reductions (K = 384: qkv, proj, fc1, GELU' products of ViT-S) take the form that prefetches the token operand through
+    // registers (gemm_bf16_areg.hip): -7 .. -12 % per launch, where the first loads' latency is a large part of a 12-step tile.
+    // Measured against this kernel at bs256: K = 768 equal, K = 1152 / 1536 +7 .. +10 % (the extra LDS writes cost more than the
+    // deeper prefetch gains once the ring is in steady state), so longer reductions stay here.  DINOX_NT_AREG_MAXK moves the
+    // boundary (0 switches the register form off, 1 << 30 sends every K % 192 == 0 product to it) for A/B runs and tests.
+    const char* e = getenv("DINOX_NT_AREG_MAXK");
+    const int64_t maxk = e ? atoll(e) : 576;
     static const bool no_areg = getenv("DINOX_NT_NO_AREG") != nullptr;
-    return !no_areg && gemm_bf16_nt_areg_ok(p) ? "gemm_bf16_nt_areg" : "gemm_bf16_nt_glds";
+    return !no_areg && p.K <= maxk && gemm_bf16_nt_areg_ok(p) ? "gemm_bf16_nt_areg" : "gemm_bf16_nt_glds";
   }
   if (p.transA == 0 && p.transB == 0 && (p.K & 7) == 0) return "gemm_bf16_nt";
   if (p.transA == 1 && p.transB == 1 && (p.M & 7) == 0 && (p.N & 7) == 0) {

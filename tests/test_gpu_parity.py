@@ -92,7 +92,7 @@ def test_gemm_bf16_vs_exact(dx, tA, tB, M, N, K):
     # the MFMA-bf16 kernels must take every aligned NT / TN shape; only (0,1) falls to the fp32-MFMA kernel
     nt = "gemm_bf16_nt"
     if K % 64 == 0 and N % 8 == 0:
-        nt = "gemm_bf16_nt_areg" if K == 384 else "gemm_bf16_nt_glds"      # K = 384: token operand through the register file
+        nt = "gemm_bf16_nt_areg" if K in (384, 576) else "gemm_bf16_nt_glds"      # short K: token operand through the register file
     want = {(0, 0): nt, (1, 1): "gemm_bf16_tn_dma", (0, 1): "gemm_f32"}[(tA, tB)]
     assert used == [want], used
     close(out, ref, rtol=1e-5, atol=1e-5 * math.sqrt(K), what=f"bf16 gemm {tA}{tB} {M}x{N}x{K}")
@@ -1062,57 +1062,82 @@ def test_vit_large_16_step_matches_oracle(dx):
     assert worst < 2e-3, worst
 
 
-@pytest.mark.parametrize("M,N", [(1000, 1152), (77, 40), (128 * 9 + 5, 1536), (4096, 384), (128 * 70 + 9, 1152), (128 * 200, 1536)])
-def test_gemm_nt_areg(dx, M, N):
-    """The K = 384 form of the NT product (token operand prefetched through the register file, csrc/gemm_bf16_areg.hip): plain,
-    bias, GELU with its GELU' side tensor, bf16 and fp32 outputs, ragged M and N, against fp64 on the same bf16 operands."""
+@pytest.mark.parametrize("M,N,K", [(1000, 1152, 384), (77, 40, 384), (128 * 9 + 5, 1536, 384), (4096, 384, 384), (128 * 70 + 9, 1152, 384),
+                                   (1000, 384, 1536), (517, 392, 1152), (300, 256, 768), (40, 384, 3072), (128 * 30, 384, 576)])
+def test_gemm_nt_areg(dx, M, N, K, monkeypatch):
+    """The register-prefetch form of the NT product (csrc/gemm_bf16_areg.hip; K a multiple of 192: two blocks of six K-steps up to
+    sixteen): every epilogue it takes over from the LDS-DMA kernel -- plain, bias, GELU with its GELU' side tensor, GELU' from the side
+    tensor, fp32 residual -- bf16 and fp32 outputs, ragged M and N (including a wave whose rows are all past M), against fp64 on the
+    same bf16 operands.  (The dispatcher sends only K <= 576 to this kernel by default: DINOX_NT_AREG_MAXK lifts that here.)"""
     ops, _ = dx
-    g = torch.Generator().manual_seed(M + N)
-    K = 384
-    A, B = (torch.randn(M, K, generator=g) * 0.5).bfloat16(), (torch.randn(N, K, generator=g) * 0.5).bfloat16()
-    bias = torch.randn(N, generator=g)
+    monkeypatch.setenv("DINOX_NT_AREG_MAXK", str(1 << 30))
+    g = torch.Generator().manual_seed(M + N + K)
+    A, B = (torch.randn(M, K, generator=g) * 0.5).bfloat16(), (torch.randn(N, K, generator=g) * (6.0 / math.sqrt(K))).bfloat16()
+    bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    Ad, Bd = A.to(DEV), B.to(DEV)
     ref = A.double() @ B.double().t()
     ops.TRACE_KERNELS = []
     try:
-        c = ops.gemm(A.to(DEV), B.to(DEV), out_dtype=torch.float32)
-        cb = ops.gemm(A.to(DEV), B.to(DEV), bias=bias.to(DEV))
+        c = ops.gemm(Ad, Bd, out_dtype=torch.float32)
+        cb = ops.gemm(Ad, Bd, bias=bias.to(DEV))
         aux = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
-        act = ops.gemm(A.to(DEV), B.to(DEV), bias=bias.to(DEV), gelu=True, aux=aux, auxgrad=True)
-        assert ops.TRACE_KERNELS == ["gemm_bf16_nt_areg"] * 3, ops.TRACE_KERNELS
+        act = ops.gemm(Ad, Bd, bias=bias.to(DEV), gelu=True, aux=aux, auxgrad=True)
+        pre_aux = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        act_t = ops.gemm(Ad, Bd, bias=bias.to(DEV), gelu=True, aux=pre_aux)
+        y = ops.gemm(Ad, Bd, bias=bias.to(DEV), residual=res.to(DEV), out_dtype=torch.float32)
+        yb = ops.gemm(Ad, Bd, residual=res.to(DEV))
+        d = ops.gemm(Ad, Bd, dgelu=True, aux=aux, auxgrad=True)
+        d2 = ops.gemm(Ad, Bd, dgelu=True, aux=pre_aux)
+        auxf = torch.randn(M, N, generator=g).to(DEV)
+        d3 = ops.gemm(Ad, Bd, dgelu=True, aux=auxf, out_dtype=torch.float32)
+        assert ops.TRACE_KERNELS == ["gemm_bf16_nt_areg"] * 9, ops.TRACE_KERNELS
     finally:
         ops.TRACE_KERNELS = None
+    erf = lambda t: torch.erf(t / math.sqrt(2))
+    gelu_grad = lambda t: 0.5 * (1 + erf(t)) + t * torch.exp(-0.5 * t * t) / math.sqrt(2 * math.pi)
     close(c, ref, 1e-5, 1e-4, "plain fp32 out")
     assert rel_l2(cb.float(), ref + bias.double()) < 3e-3
     pre = ref + bias.double()
-    gel = 0.5 * pre * (1 + torch.erf(pre / math.sqrt(2)))
-    dg = 0.5 * (1 + torch.erf(pre / math.sqrt(2))) + pre * torch.exp(-0.5 * pre * pre) / math.sqrt(2 * math.pi)
-    assert rel_l2(act.float(), gel) < 3e-3 and rel_l2(aux.float(), dg) < 3e-3
+    assert rel_l2(act.float(), 0.5 * pre * (1 + erf(pre))) < 3e-3 and rel_l2(aux.float(), gelu_grad(pre)) < 3e-3
+    assert rel_l2(act_t.float(), 0.5 * pre * (1 + erf(pre))) < 3e-3 and rel_l2(pre_aux.float(), pre) < 3e-3
+    close(y, pre + res.double(), 1e-5, 1e-4, "bias + residual, fp32 out")
+    assert rel_l2(yb.float(), ref + res.double()) < 3e-3
+    assert rel_l2(d.float(), ref * aux.float().double().cpu()) < 3e-3
+    assert rel_l2(d2.float(), ref * gelu_grad(pre_aux.float().double().cpu())) < 3e-3
+    close(d3, ref * gelu_grad(auxf.double().cpu()), 1e-4, 1e-3, "GELU' from an fp32 side tensor, fp32 out")
 
 
-@pytest.mark.parametrize("workers", [0, 768])
-def test_gemm_nt_areg_full_size_repeatable(dx, workers, monkeypatch):
-    """BASELINE size (M = 512 views x 201 tokens, qkv product) through the register-prefetch NT kernel, 40 launches back to back:
-    the kernel has no atomics, so every launch must reproduce the first bit for bit (a missed wait on a staged slice shows up as a
-    sporadic difference), and sampled rows must match fp64.  ``workers`` = 0: one workgroup per tile (the default); 768: the
-    persistent form with cross-tile prefetch (DINOX_NT_AREG_WORKERS).  This test is what caught LDS reads left in flight across
-    the barrier in front of the accumulator parking (one tile in ~1e5 multiplied by parked fp32 words)."""
+@pytest.mark.parametrize("N,K,res", [(1152, 384, False), (384, 1536, True)])
+def test_gemm_nt_areg_full_size_repeatable(dx, N, K, res, monkeypatch):
+    """BASELINE size (M = 512 views x 201 tokens; the qkv product and the fc2 product with its fp32 residual) through the
+    register-prefetch NT kernel, 120 launches back to back: the kernel has no atomics, so every launch must reproduce the first bit
+    for bit (a missed wait on a staged slice shows up as a sporadic difference), and sampled rows must match fp64.  This test is
+    what caught LDS reads left in flight across the barrier in front of the accumulator parking (one tile in ~1e5 multiplied by
+    parked fp32 words)."""
     ops, _ = dx
-    monkeypatch.setenv("DINOX_NT_AREG_WORKERS", str(workers))
+    monkeypatch.setenv("DINOX_NT_AREG_MAXK", str(1 << 30))
     g = torch.Generator(device=DEV).manual_seed(0)
-    M, N, K = 512 * 201, 1152, 384
+    M = 512 * 201
     A = (torch.randn(M, K, device=DEV, generator=g) * 0.5).bfloat16()
     B = (torch.randn(N, K, device=DEV, generator=g) * 0.5).bfloat16()
     bias = torch.randn(N, device=DEV, generator=g)
-    first = ops.gemm(A, B, bias=bias)
+    r = torch.randn(M, N, device=DEV, generator=g) if res else None
+    run = lambda: ops.gemm(A, B, bias=bias, residual=r, out_dtype=torch.float32 if res else None)
+    ops.TRACE_KERNELS = []
+    try:
+        first = run()
+        assert ops.TRACE_KERNELS == ["gemm_bf16_nt_areg"], ops.TRACE_KERNELS
+    finally:
+        ops.TRACE_KERNELS = None
     for _ in range(120):
-        assert torch.equal(ops.gemm(A, B, bias=bias), first)
+        assert torch.equal(run(), first)
     assert bool(torch.isfinite(first.float()).all())
     rows = torch.randint(0, M, (256,), device=DEV, generator=g)
-    ref = A[rows].double() @ B.double().t() + bias.double()
+    ref = A[rows].double() @ B.double().t() + bias.double() + (r[rows].double() if res else 0)
     assert rel_l2(first[rows].float(), ref) < 3e-3
 
 
-@pytest.mark.parametrize("K,N", [(1024, 1024), (1536, 384), (4096, 1024)])
+@pytest.mark.parametrize("K,N", [(1024, 1024), (1600, 384), (4096, 1024)])
 def test_gemm_nt_glds_repeatable(dx, K, N):
     """The LDS-DMA ring NT kernel at long K, 60 launches back to back, bit for bit.  K = 1024 and 4096 (ViT-L widths) end the K loop
     on ring slot 1, which is also where two waves park their accumulators: the last step's LDS reads must have returned before the

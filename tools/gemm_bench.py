@@ -40,6 +40,12 @@ dbd = torch.empty(D, device=dev)
 case("dW2   TN M384 N1536  (+db)       ", lambda: ops.gemm(x, xh, transA=True, transB=True, out_dtype=torch.float32, colsum_out=dbd), 2 * M * D * H, M * H * 2 + M * D * 2)
 case("dWp   TN M384 N384   (+db)       ", lambda: ops.gemm(x, x, transA=True, transB=True, out_dtype=torch.float32, colsum_out=dbd), 2 * M * D * D, 2 * M * D * 2)
 
+if os.environ.get("VITB"):
+    Db = 768
+    xb_, wqb, wpb = rb(M, Db), rb(3 * Db, Db), rb(Db, Db)
+    bqb, bdb, resb = rf(3 * Db), rf(Db), rf(M, Db)
+    case("vitb qkv  NT K768 N2304 bias   ", lambda: ops.gemm(xb_, wqb, bias=bqb), 2 * M * Db * 3 * Db, M * Db * 2 + M * 3 * Db * 2)
+    case("vitb proj NT K768 N768 bias+res", lambda: ops.gemm(xb_, wpb, bias=bdb, residual=resb, out_dtype=torch.float32), 2 * M * Db * Db, M * Db * 2 + 2 * M * Db * 4)
 case("mlpT  fused fc1+gelu+fc2+res     ", lambda: ops.mlp_fwd_fused(x, w1, bh, w2, bd, res), 4 * M * D * H, M * D * 2 + 2 * M * D * 4)
 if os.environ.get("SQUARE"):
     S = int(os.environ["SQUARE"])

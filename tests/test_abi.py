@@ -62,3 +62,33 @@ def test_gemm_args_struct_layout():
     assert ctypes.sizeof(GemmArgs) == 3 * 8 + 3 * 8 + 3 * 8 + 4 * 8 + 5 * 4 + 4 + 2 * 8 + 8 + 8 + 8 + 8
     assert GemmArgs.alpha.offset == 13 * 8 + 5 * 4
     assert GemmArgs.bias.offset == 13 * 8 + 24
+
+
+def test_gemm_dispatch_by_shape(monkeypatch):
+    """dinox_gemm_kernel_name is host logic (shapes, strides, alignment of the pointer VALUES; nothing is dereferenced): the
+    hot-path shapes must reach the kernels DESIGN.md section 4 prices them on -- K = 384 NT products the register-prefetch kernel
+    with every epilogue it took over, longer reductions the LDS-DMA ring, dW products the split-K TN kernel."""
+    from dinox import _lib
+    from dinox.ops import BF16, F32, EPI_BIAS, EPI_DGELU, EPI_GELU, EPI_RESIDUAL
+
+    def name(M, N, K, tA=0, tB=0, epi=0, out=BF16, aux=0, res=0):
+        g = _lib.GemmArgs(A=0x10000, B=0x20000, C=0x30000, M=M, N=N, K=K, lda=(M if tA else K), ldb=(N if tB else K), ldc=N, batch=1,
+                          strideA=0, strideB=0, strideC=M * N, transA=tA, transB=tB, in_dtype=BF16, out_dtype=out, epilogue=epi,
+                          alpha=1.0, bias=0x40000 if epi & EPI_BIAS else None, residual=res or None, ldr=N, aux=aux or None, ldaux=N,
+                          colsum=None)
+        return _lib.lib.dinox_gemm_kernel_name(ctypes.byref(g)).decode()
+
+    monkeypatch.delenv("DINOX_NT_AREG_MAXK", raising=False)
+    T = 512 * 201
+    assert name(T, 1152, 384, epi=EPI_BIAS) == "gemm_bf16_nt_areg"                                  # qkv
+    assert name(T, 384, 384, epi=EPI_BIAS | EPI_RESIDUAL, out=F32, res=0x50000) == "gemm_bf16_nt_areg"   # proj
+    assert name(T, 1536, 384, epi=EPI_BIAS | EPI_GELU, aux=0x60000) == "gemm_bf16_nt_areg"          # fc1
+    assert name(T, 1536, 384, epi=EPI_DGELU, aux=0x60000) == "gemm_bf16_nt_areg"                    # GELU' product
+    assert name(T, 384, 1536, epi=EPI_BIAS | EPI_RESIDUAL, out=F32, res=0x50000) == "gemm_bf16_nt_glds"  # fc2
+    assert name(T, 384, 1152) == "gemm_bf16_nt_glds"                                                # dX of qkv
+    assert name(T // 2, 1024, 1024) == "gemm_bf16_nt_glds"                                          # ViT-L width
+    assert name(1536, 384, T, tA=1, tB=1, out=F32) == "gemm_bf16_tn_dma"                            # dW1
+    monkeypatch.setenv("DINOX_NT_AREG_MAXK", str(1 << 30))
+    assert name(T, 384, 1536) == "gemm_bf16_nt_areg" and name(T // 2, 1024, 1024) == "gemm_bf16_nt_glds"   # K % 192 rules
+    monkeypatch.setenv("DINOX_NT_AREG_MAXK", "0")
+    assert name(T, 1152, 384, epi=EPI_BIAS) == "gemm_bf16_nt_glds"

@@ -26,6 +26,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include <type_traits>
 
 namespace dinox {
 
@@ -98,6 +99,34 @@ __device__ __forceinline__ void store_tile(bf16_t* __restrict__ dst, int64_t row
     const int r = row0 + acc_row(e, lane >> 5);
     if (r < n_valid) dst[(int64_t)r * row_stride + d0 + (lane & 31)] = f32_to_bf16(x[e] * scale);
   }
+}
+
+// Store a 32-row x 64-column block of fp32 accumulators (two 32x32 tiles: columns 0..31 and 32..63 of one head) as bf16 rows of a
+// strided matrix, THROUGH a per-wave LDS scratch of 32 rows x ST_ROWB bytes: the accumulator layout puts one column per lane, so a
+// direct store is 32 two-byte stores per lane, each behind its own row test (about 500 instructions per wave: measured 29 of
+// 110 us in the forward kernel); re-read by rows, a lane stores four 16-byte pieces and a row leaves as one 128-byte segment.
+// dst must be 16-byte aligned and row_stride a multiple of 8 elements.
+constexpr int ST_ROWB = 144;                       // 128 B of data + 16: rows r and r + 4 (the two lane halves) land in different banks
+constexpr int ST_BYTES = 32 * ST_ROWB;
+__device__ __forceinline__ void store_block(bf16_t* __restrict__ dst, int64_t row_stride, int row0, int n_valid, const f32x16& x0,
+                                            const f32x16& x1, char* scratch, int lane) {
+  const int col = lane & 31, hl = lane >> 5;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    char* rowp = scratch + acc_row(e, hl) * ST_ROWB + col * 2;
+    *reinterpret_cast<bf16_t*>(rowp) = f32_to_bf16(x0[e]);
+    *reinterpret_cast<bf16_t*>(rowp + 64) = f32_to_bf16(x1[e]);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int r = (lane >> 3) + 8 * it, c = lane & 7;
+    const uint4 v = *reinterpret_cast<const uint4*>(scratch + r * ST_ROWB + c * 16);
+    if (row0 + r < n_valid) *reinterpret_cast<uint4*>(dst + (int64_t)(row0 + r) * row_stride + c * 8) = v;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
 }
 
 // ------------------------------------------------------------------------------------------ forward
@@ -230,6 +259,18 @@ __device__ __forceinline__ bf16x8 rd_tr(const char* img, const TrAddr& a, int ss
   return __builtin_bit_cast(bf16x8, v);
 }
 
+// Two transposed 8-byte LDS reads -> one B fragment.  The __restrict__ parameters are not decoration: after inlining they give the
+// two reads alias-scope metadata, and hipcc's waitcnt insertion only falls back to "wait for every LDS-DMA in flight" (vmcnt(0),
+// which in the persistent forward kernel means the NEXT pair's images, requested a moment earlier) for LDS reads that carry none.
+__device__ __forceinline__ bf16x8 rd_tr_pair(const char* __restrict__ p0, const char* __restrict__ p1) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p1);
+  s16x8 v;
+  v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+  v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+  return __builtin_bit_cast(bf16x8, v);
+}
+
 // ------------------------------------------------------------------------------------------ forward, persistent
 typedef __attribute__((address_space(3))) void at_lds_void;
 typedef __attribute__((address_space(1))) const void at_gbl_void;
@@ -262,6 +303,7 @@ __global__ __launch_bounds__(512) void attn_fwd_bf16_persist(const bf16_t* __res
   const int64_t rs = 3 * (int64_t)C;
   const int npad = nkt * 32, img_bytes = npad * 128;
   float* inv_s = reinterpret_cast<float*>(smem + 4 * img_bytes) + wv * 32;
+  char* const st_scratch = smem + 4 * img_bytes + 8 * 32 * (int)sizeof(float) + wv * ST_BYTES;     // this wave's output staging area
   const int hl = lane >> 5;
   int pair = blockIdx.x;
   if (pair >= npairs) return;
@@ -281,6 +323,29 @@ __global__ __launch_bounds__(512) void attn_fwd_bf16_persist(const bf16_t* __res
   bf16x8 qnext[4];
   q_frags(qnext, pair, wv);                 // prefetched one pair ahead, together with that pair's images
   issue(pair, 0);
+  // Output stores are DEFERRED by one pair: the tile a wave finishes in iteration i is stored at the top of iteration i + 1, after
+  // that iteration's wait and barrier.  vmcnt counts stores as well as loads, so with the stores at the end of an iteration the
+  // vmcnt(0) at the top of the next one also waited for them to be acknowledged: 29 of 110 us at the hot-path shape (ablation:
+  // without its stores the kernel ran 29 us faster even with all of its arithmetic removed).  Issued at the top, they have a whole
+  // pair's arithmetic to drain.  The registers that hold the pending tile are free at that point (no score tile is live).
+  f32x16 pend[2];
+  float pend_lse = 0.f;
+  int pend_pair = -1, pend_q0 = 0;          // wave-uniform
+  auto store_pending = [&]() {
+    const int pb = pend_pair / heads, ph = pend_pair % heads;
+    if (hl == 0 && pend_q0 + lane < N) lse[((int64_t)pb * heads + ph) * N + pend_q0 + lane] = pend_lse;
+    store_block(o + (int64_t)pb * N * C + ph * AT_D, C, pend_q0, N, pend[0], pend[1], st_scratch, lane);
+  };
+  // The first pair's loads are retired here, and hipcc is SHOWN that they are (a use of the fragments, an LDS read of the image):
+  // it does not see through the asm, and with loads still pending in its own bookkeeping at the loop head it puts a vmcnt(0) in
+  // front of the first MFMA of every iteration -- which waits for the NEXT pair's images, requested a moment earlier.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qnext[ks]));
+    const float seen = *reinterpret_cast<const volatile float*>(smem + lane * 4);
+    asm volatile("" ::"v"(seen));
+  }
   for (int it = 0; pair < npairs; pair += gridDim.x, ++it) {
     const int buf = it & 1;
     bf16x8 qf[4];
@@ -294,10 +359,14 @@ __global__ __launch_bounds__(512) void attn_fwd_bf16_persist(const bf16_t* __res
       q_frags(qnext, nxt, wv);
       issue(nxt, buf ^ 1);
     }
+    if (it > 0) store_pending();
     const char* kimg = smem + (2 * buf) * img_bytes;
     const char* vimg = kimg + img_bytes;
     const int b = pair / heads, hh = pair % heads;
-    for (int qb = wv; qb * 32 < N; qb += nw) {
+    // One query block of this pair.  DEFER (the wave's last block, always executed so that the pending tile is redefined in every
+    // iteration and is never live across another block's arithmetic): keep the normalised tile for the next iteration's stores.
+    auto do_block = [&](int qb, auto defer_c) {
+      constexpr bool DEFER = decltype(defer_c)::value;
       if (qb != wv) q_frags(qf, pair, qb);               // more query blocks than waves (N > 256): fetched on demand
       const int q0 = qb * 32;
       // Key tile kt sits 4096 B after tile kt-1 in the image (32 rows = four 1-KiB row groups, swizzle terms unchanged), so
@@ -359,12 +428,7 @@ __global__ __launch_bounds__(512) void attn_fwd_bf16_persist(const bf16_t* __res
             const bf16x8 pa = acc_as_a(st[kt], ss);
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
-              const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vt[ss][dt][0] + kt * 4096));
-              const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vt[ss][dt][1] + kt * 4096));
-              s16x8 v;
-              v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
-              v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
-              oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, __builtin_bit_cast(bf16x8, v), oacc[dt], 0, 0, 0);
+              oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, rd_tr_pair(vt[ss][dt][0] + kt * 4096, vt[ss][dt][1] + kt * 4096), oacc[dt], 0, 0, 0);
             }
           }
         }
@@ -415,21 +479,14 @@ __global__ __launch_bounds__(512) void attn_fwd_bf16_persist(const bf16_t* __res
           const bf16x8 pa = acc_as_a(st, ss);
 #pragma unroll
           for (int dt = 0; dt < 2; ++dt) {
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vt[ss][dt][0] + kt * 4096));
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vt[ss][dt][1] + kt * 4096));
-            s16x8 v;
-            v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
-            v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
-            oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, __builtin_bit_cast(bf16x8, v), oacc[dt], 0, 0, 0);
+            oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, rd_tr_pair(vt[ss][dt][0] + kt * 4096, vt[ss][dt][1] + kt * 4096), oacc[dt], 0, 0, 0);
           }
         }
       }
       }
       sum += __shfl_xor(sum, 32, 64);
-      if (hl == 0) {
-        inv_s[lane] = 1.0f / sum;
-        if (q0 + lane < N) lse[((int64_t)b * heads + hh) * N + q0 + lane] = mx + __logf(sum);
-      }
+      if (hl == 0) inv_s[lane] = 1.0f / sum;
+      const float lse_q = mx + __logf(sum);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -443,11 +500,23 @@ __global__ __launch_bounds__(512) void attn_fwd_bf16_persist(const bf16_t* __res
         }
       }
       __builtin_amdgcn_wave_barrier();
-      bf16_t* ob = o + (int64_t)b * N * C + hh * AT_D;
-      store_tile(ob, C, q0, N, 0, oacc[0], 1.0f, lane);
-      store_tile(ob, C, q0, N, 32, oacc[1], 1.0f, lane);
-    }
+      if (DEFER) {                                        // the wave's last (for N <= 256: only) block of this pair: stored next iteration
+        pend[0] = oacc[0];
+        pend[1] = oacc[1];
+        pend_lse = lse_q;
+        pend_pair = pair;
+        pend_q0 = q0;
+      } else {
+        if (hl == 0 && q0 + lane < N) lse[((int64_t)b * heads + hh) * N + q0 + lane] = lse_q;
+        store_block(o + (int64_t)b * N * C + hh * AT_D, C, q0, N, oacc[0], oacc[1], st_scratch, lane);
+      }
+    };
+    int qb = wv;
+    if constexpr (NKT == 0)                                                    // NKT > 0: one wave per query block (N <= 224)
+      for (; (qb + nw) * 32 < N; qb += nw) do_block(qb, std::false_type{});    // more query blocks than waves (N > 256 only)
+    do_block(qb, std::true_type{});
   }
+  store_pending();
 }
 
 // ------------------------------------------------------------------------------------------ backward: dQ
@@ -483,7 +552,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_bf16(const bf16_t* __restrict
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
-  if (!active) return;
+  f32x16 dq[2];
+  zero16(dq[0]);
+  zero16(dq[1]);
+  if (active) {
   float delta = 0.f;
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks)
@@ -492,9 +564,6 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_bf16(const bf16_t* __restrict
   delta += __shfl_xor(delta, 32, 64);
   if (hl == 0 && q0 + lane < N) delta_ws[((int64_t)b * heads + hh) * N + q0 + lane] = delta;   // re-used by the dK/dV kernel
 
-  f32x16 dq[2];
-  zero16(dq[0]);
-  zero16(dq[1]);
   RowAddr ra;
   TrAddr ta;
   ra.init(lane);
@@ -527,9 +596,12 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_bf16(const bf16_t* __restrict
       for (int dt = 0; dt < 2; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, rd_tr(kimg, ta, ss, dt, kt), dq[dt], 0, 0, 0);
     }
   }
+  // (direct stores: staging them through the images' LDS needs a workgroup barrier first, and waves that finish early then wait
+  //  instead of storing under the others' arithmetic -- measured 4 % slower for the two backward kernels together)
   bf16_t* dqb = dqkv + (int64_t)b * N * rs + hh * AT_D;
   store_tile(dqb, rs, q0, N, 0, dq[0], 1.0f, lane);
   store_tile(dqb, rs, q0, N, 32, dq[1], 1.0f, lane);
+  }   // active
 }
 
 // ------------------------------------------------------------------------------------------ backward: dK, dV
@@ -565,10 +637,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_bf16(const bf16_t* __restric
   load_row_frags(vf, base + (int64_t)krow * rs + 2 * C, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();                                                   // DMA pieces + the LDS statistics of every wave
-  if (kb * 32 >= N) return;
-
+  const bool active = kb * 32 < N;                                   // wave-uniform
   f32x16 dk[2], dv[2];
   zero16(dk[0]); zero16(dk[1]); zero16(dv[0]); zero16(dv[1]);
+  if (active) {
   RowAddr ra;
   TrAddr ta;
   ra.init(lane);
@@ -615,6 +687,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_bf16(const bf16_t* __restric
   store_tile(dkb, rs, k0, N, 32, dk[1], 1.0f, lane);
   store_tile(dvb, rs, k0, N, 0, dv[0], 1.0f, lane);
   store_tile(dvb, rs, k0, N, 32, dv[1], 1.0f, lane);
+  }   // active
 }
 
 // ------------------------------------------------------------------------------------------ launchers
@@ -638,7 +711,7 @@ int launch_attention_bf16_fwd(const void* qkv, void* o, float* lse, int B, int N
   const float sc = 1.0f / sqrtf((float)d);
   {
     const int nw = nblk < 8 ? nblk : 8;
-    const size_t lds = (size_t)4 * nblk * 32 * 128 + 8 * 32 * sizeof(float);
+    const size_t lds = (size_t)4 * nblk * 32 * 128 + 8 * 32 * sizeof(float) + 8 * (size_t)ST_BYTES;     // images, 1/rowsum, output staging
     static const bool off = getenv("DINOX_ATTN_NO_PERSIST") != nullptr;
     if (lds <= 160 * 1024 && !off) {
       const int npairs = B * heads;
@@ -669,7 +742,7 @@ int launch_attention_bf16_fwd(const void* qkv, void* o, float* lse, int B, int N
 int launch_attention_bf16_bwd(const void* d_o, const void* qkv, const void* o, const float* lse, void* dqkv, float* ws, int B,
                               int N, int heads, int d, hipStream_t st) {
   if (!ws) return DINOX_EUNSUPPORTED;
-  if (d != AT_D || N > 544 || ((uintptr_t)qkv & 15) || ((uintptr_t)o & 15) || ((uintptr_t)d_o & 15)) return DINOX_EUNSUPPORTED;
+  if (d != AT_D || N > 544 || ((uintptr_t)qkv & 15) || ((uintptr_t)o & 15) || ((uintptr_t)d_o & 15) || ((uintptr_t)dqkv & 15)) return DINOX_EUNSUPPORTED;
   int nblk, nwg, waves;
   geometry(N, nblk, nwg, waves);
   const float sc = 1.0f / sqrtf((float)d);

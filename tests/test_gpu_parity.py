@@ -203,7 +203,7 @@ def test_attention_module_golden(dx, mode):
             assert rel_l2(dict(m.named_parameters())[k].grad, v) < 2.5e-2, k
 
 
-@pytest.mark.parametrize("B,N,h,d", [(2, 201, 6, 64), (1, 19, 2, 32), (3, 64, 1, 64), (1, 261, 2, 64), (2, 7, 2, 16)])
+@pytest.mark.parametrize("B,N,h,d", [(2, 201, 6, 64), (1, 19, 2, 32), (3, 64, 1, 64), (1, 261, 2, 64), (2, 7, 2, 16), (40, 250, 6, 64), (50, 37, 6, 64), (3, 530, 2, 64), (60, 201, 6, 64)])
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 def test_attention_core_vs_np(dx, B, N, h, d, mode):
     ops, _ = dx

@@ -1,0 +1,181 @@
+// tile_probe.hip -- K loops of NT bf16 GEMM tiles of different shapes, WITHOUT epilogue: what does the feed + MFMA part of a kernel
+// cost for 128x128 (four waves, three workgroups per CU: the shipped shape), 256x128, 128x384 (full rows of the N = 384 products) and
+// 256x256 tiles?  Companion of dma_probe.hip: that one prices the memory system, this one adds the LDS fragment reads, the MFMAs and
+// the barrier structure, and nothing else (each lane stores one checksum word per tile).
+//
+// Same building blocks as csrc/gemm_bf16_glds.hip: operands global -> LDS by global_load_lds_dwordx4 into a ring of STAGES slots
+// ([rows][32 k] images, 64 B per row, 16-B chunk c of row r stored at c ^ ((r >> 2) & 3)), counted vmcnt + one barrier per K-step,
+// v_mfma_f32_32x32x16_bf16, XCD-contiguous tile order (N fastest).
+// Build: hipcc --offload-arch=gfx950 -O3 -o tools/tile_probe tools/tile_probe.hip        Run (GPU box): tools/tile_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_void;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define CK(x)                                                                            \
+  do {                                                                                   \
+    hipError_t e_ = (x);                                                                 \
+    if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } \
+  } while (0)
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// BM x BN tile, WM x WN waves (each (BM / WM) x (BN / WN), multiples of 32), STAGES ring slots of BK = 32, WGPC workgroups per CU
+template <int BM, int BN, int WM, int WN, int STAGES, int WGPC>
+__global__ __launch_bounds__(WM * WN * 64, WGPC) void tile_kloop(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B,
+                                                                 float* __restrict__ out, int M, int N, int K, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int WAVES = WM * WN, TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int ATILE = BM * 64, BTILE = BN * 64, SLOT = ATILE + BTILE;
+  constexpr int NQA = BM / 16 / WAVES, NQB = BN / 16 / WAVES;      // DMA instructions (16 rows x 64 B) per wave and operand
+  static_assert(NQA >= 1 && NQB >= 1, "tile too small for the wave count");
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wv / WN, wc = wv % WN;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  const long m0 = (long)tm * BM, n0 = (long)tn * BN;
+  const char* abase = (const char*)(A + m0 * K);
+  const char* bbase = (const char*)(B + n0 * K);
+  unsigned avoff[NQA], bvoff[NQB];
+#pragma unroll
+  for (int q = 0; q < NQA; ++q) {
+    int row = (wv * NQA + q) * 16 + (lane >> 2);
+    const int c = (lane & 3) ^ ((row >> 2) & 3);
+    row = m0 + row < M ? row : (int)(M - 1 - m0);
+    avoff[q] = (unsigned)(((long)row * K + c * 8) * 2);
+  }
+#pragma unroll
+  for (int q = 0; q < NQB; ++q) {
+    int row = (wv * NQB + q) * 16 + (lane >> 2);
+    const int c = (lane & 3) ^ ((row >> 2) & 3);
+    row = n0 + row < N ? row : (int)(N - 1 - n0);
+    bvoff[q] = (unsigned)(((long)row * K + c * 8) * 2);
+  }
+  auto stage = [&](int slot, int kt) {
+    char* sa = smem + slot * SLOT + wv * (NQA * 1024);
+    char* sb = smem + slot * SLOT + ATILE + wv * (NQB * 1024);
+#pragma unroll
+    for (int q = 0; q < NQA; ++q) __builtin_amdgcn_global_load_lds((gbl_void*)(abase + avoff[q] + kt * 64), (lds_void*)(sa + q * 1024), 16, 0, 0);
+#pragma unroll
+    for (int q = 0; q < NQB; ++q) __builtin_amdgcn_global_load_lds((gbl_void*)(bbase + bvoff[q] + kt * 64), (lds_void*)(sb + q * 1024), 16, 0, 0);
+  };
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const int nk = K / 32, frow = lane & 31, fh = lane >> 5;
+#pragma unroll
+  for (int d = 0; d < STAGES - 1; ++d)
+    if (d < nk) stage(d, d);
+  int slot = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + STAGES - 1 <= nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * (NQA + NQB)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + STAGES - 1 < nk) stage(slot == 0 ? STAGES - 1 : slot - 1, kt + STAGES - 1);
+    const char* sa = smem + slot * SLOT;
+    const char* sb = sa + ATILE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[TM], bfr[TN];
+      const int kc = 2 * ks + fh;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int ra = wr * (BM / WM) + i * 32 + frow;
+        af[i] = *reinterpret_cast<const bf16x8*>(sa + ra * 64 + ((kc ^ ((ra >> 2) & 3)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int rb = wc * (BN / WN) + j * 32 + frow;
+        bfr[j] = *reinterpret_cast<const bf16x8*>(sb + rb * 64 + ((kc ^ ((rb >> 2) & 3)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    slot = slot == STAGES - 1 ? 0 : slot + 1;
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s += acc[i][j][e];
+  out[(long)blockIdx.x * (WAVES * 64) + threadIdx.x] = s;
+}
+
+template <int BM, int BN, int WM, int WN, int STAGES, int WGPC>
+static void run(const char* what, const uint16_t* A, const uint16_t* B, float* out, int M, int N, int K) {
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  const size_t lds = (size_t)STAGES * (BM + BN) * 64;
+  auto kern = tile_kloop<BM, BN, WM, WN, STAGES, WGPC>;
+  if (lds > 64 * 1024) CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  const dim3 grid(tiles_m * tiles_n), block(WM * WN * 64);
+  for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(kern, grid, block, lds, 0, A, B, out, M, N, K, tiles_n);
+  CK(hipDeviceSynchronize());
+  float best = 1e30f;
+  for (int r = 0; r < 7; ++r) {
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(kern, grid, block, lds, 0, A, B, out, M, N, K, tiles_n);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    best = ms < best ? ms : best;
+  }
+  const double fl = 2.0 * M * N * K, into_lds = ((double)tiles_n * M * K + (double)tiles_m * N * K) * 2;
+  printf("  %-34s %4d x %-4d tiles %5d  LDS %3zu KiB  %7.1f us  %6.0f TFLOP/s  %5.2f GB into LDS (%5.1f TB/s)\n", what, BM, BN,
+         tiles_m * tiles_n, lds >> 10, best * 1e3, fl / (best * 1e-3) / 1e12, into_lds / 1e9, into_lds / (best * 1e-3) / 1e12);
+}
+
+int main() {
+  const int M = 512 * 201;
+  uint16_t *A, *B;
+  float* out;
+  const size_t na = (size_t)M * 1536, nb = (size_t)1536 * 1536;
+  CK(hipMalloc(&A, na * 2));
+  CK(hipMalloc(&B, nb * 2));
+  CK(hipMalloc(&out, (size_t)64 << 20));
+  {   // bf16 values around +-0.5 (0x3Exx / 0xBExx): finite, not constant
+    uint16_t* h = (uint16_t*)malloc(na * 2);
+    uint32_t s = 12345u;
+    for (size_t i = 0; i < na; ++i) { s = s * 1664525u + 1013904223u; h[i] = (uint16_t)(0x3E00u | ((s >> 9) & 0x80FFu)); }
+    CK(hipMemcpy(A, h, na * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(B, h, nb * 2, hipMemcpyHostToDevice));
+    free(h);
+  }
+  struct { const char* name; int N, K; } shapes[] = {{"qkv  (N 1152, K 384)", 1152, 384}, {"fc1  (N 1536, K 384)", 1536, 384},
+                                                    {"proj (N 384,  K 384)", 384, 384}, {"fc2  (N 384,  K 1536)", 384, 1536}};
+  printf("K loops only (no epilogue), M = %d tokens, best of 7\n", M);
+  for (auto& sh : shapes) {
+    printf("%s\n", sh.name);
+    const int N = sh.N, K = sh.K;
+    run<128, 128, 2, 2, 3, 3>("128x128, 4 waves, 3 stages, 3 wg/CU", A, B, out, M, N, K);
+    run<256, 128, 2, 2, 3, 2>("256x128, 4 waves, 3 stages, 2 wg/CU", A, B, out, M, N, K);
+    run<256, 128, 4, 2, 3, 1>("256x128, 8 waves, 3 stages, 1 wg/CU", A, B, out, M, N, K);
+    run<128, 384, 2, 4, 3, 1>("128x384, 8 waves, 3 stages, 1 wg/CU", A, B, out, M, N, K);
+    run<128, 384, 2, 4, 2, 2>("128x384, 8 waves, 2 stages, 2 wg/CU", A, B, out, M, N, K);
+    run<256, 256, 2, 4, 3, 1>("256x256, 8 waves, 3 stages, 1 wg/CU", A, B, out, M, N, K);
+    run<256, 384, 4, 2, 3, 1>("256x384, 8 waves, 3 stages, 1 wg/CU", A, B, out, M, N, K);
+  }
+  return 0;
+}

@@ -1107,6 +1107,40 @@ def test_gemm_nt_areg(dx, M, N, K, monkeypatch):
     close(d3, ref * gelu_grad(auxf.double().cpu()), 1e-4, 1e-3, "GELU' from an fp32 side tensor, fp32 out")
 
 
+@pytest.mark.parametrize("M,N,K", [(1000, 1152, 384), (128 * 9 + 5, 1536, 384), (40, 768, 384), (4096, 1536, 576), (128 * 300, 1152, 384)])
+def test_gemm_nt_wide(dx, M, N, K, monkeypatch):
+    """The opt-in 128 x 384-tile form of the wide short-K products (csrc/gemm_bf16_wide.hip, DINOX_NT_WIDE=1): plain + bias, GELU with
+    either side tensor, GELU' from either side tensor, ragged M (including a wave whose rows are all past M), against fp64 on the same
+    bf16 operands."""
+    ops, _ = dx
+    monkeypatch.setenv("DINOX_NT_WIDE", "1")
+    g = torch.Generator().manual_seed(M + N + K)
+    A, B = (torch.randn(M, K, generator=g) * 0.5).bfloat16(), (torch.randn(N, K, generator=g) * (6.0 / math.sqrt(K))).bfloat16()
+    bias = torch.randn(N, generator=g)
+    Ad, Bd = A.to(DEV), B.to(DEV)
+    ref = A.double() @ B.double().t()
+    ops.TRACE_KERNELS = []
+    try:
+        cb = ops.gemm(Ad, Bd, bias=bias.to(DEV))
+        aux = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        act = ops.gemm(Ad, Bd, bias=bias.to(DEV), gelu=True, aux=aux, auxgrad=True)
+        pre_aux = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        act_t = ops.gemm(Ad, Bd, bias=bias.to(DEV), gelu=True, aux=pre_aux)
+        d = ops.gemm(Ad, Bd, dgelu=True, aux=aux, auxgrad=True)
+        d2 = ops.gemm(Ad, Bd, dgelu=True, aux=pre_aux)
+        assert ops.TRACE_KERNELS == ["gemm_bf16_nt_wide"] * 5, ops.TRACE_KERNELS
+    finally:
+        ops.TRACE_KERNELS = None
+    erf = lambda t: torch.erf(t / math.sqrt(2))
+    gelu_grad = lambda t: 0.5 * (1 + erf(t)) + t * torch.exp(-0.5 * t * t) / math.sqrt(2 * math.pi)
+    pre = ref + bias.double()
+    assert rel_l2(cb.float(), pre) < 3e-3
+    assert rel_l2(act.float(), 0.5 * pre * (1 + erf(pre))) < 3e-3 and rel_l2(aux.float(), gelu_grad(pre)) < 3e-3
+    assert rel_l2(act_t.float(), 0.5 * pre * (1 + erf(pre))) < 3e-3 and rel_l2(pre_aux.float(), pre) < 3e-3
+    assert rel_l2(d.float(), ref * aux.float().double().cpu()) < 3e-3
+    assert rel_l2(d2.float(), ref * gelu_grad(pre_aux.float().double().cpu())) < 3e-3
+
+
 @pytest.mark.parametrize("N,K,res", [(1152, 384, False), (384, 1536, True)])
 def test_gemm_nt_areg_full_size_repeatable(dx, N, K, res, monkeypatch):
     """BASELINE size (M = 512 views x 201 tokens; the qkv product and the fc2 product with its fp32 residual) through the

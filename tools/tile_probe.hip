@@ -29,9 +29,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 // BM x BN tile, WM x WN waves (each (BM / WM) x (BN / WN), multiples of 32), STAGES ring slots of BK = 32, WGPC workgroups per CU
-template <int BM, int BN, int WM, int WN, int STAGES, int WGPC>
+template <int BM, int BN, int WM, int WN, int STAGES, int WGPC, int EPI>
 __global__ __launch_bounds__(WM * WN * 64, WGPC) void tile_kloop(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B,
-                                                                 float* __restrict__ out, int M, int N, int K, int tiles_n) {
+                                                                 float* __restrict__ out, uint16_t* __restrict__ C, int M, int N, int K,
+                                                                 int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int WAVES = WM * WN, TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int ATILE = BM * 64, BTILE = BN * 64, SLOT = ATILE + BTILE;
@@ -110,32 +111,68 @@ __global__ __launch_bounds__(WM * WN * 64, WGPC) void tile_kloop(const uint16_t*
     }
     slot = slot == STAGES - 1 ? 0 : slot + 1;
   }
-  float s = 0.f;
+  if (EPI == 0) {
+    float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s += acc[i][j][e];
+    out[(long)blockIdx.x * (WAVES * 64) + threadIdx.x] = s;
+    return;
+  }
+  // EPI 1: the kernels' epilogue without its arithmetic -- park 16 rows of the wave's block in LDS, re-read by rows, 16-byte bf16 stores
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  constexpr int ROWB = 128 * TN;                               // bytes of one parked row (32 TN floats)
+  char* park = smem + wv * (16 * ROWB);
+  uint16_t* cblk = C + (m0 + wr * (BM / WM)) * N + n0 + wc * (BN / WN);
+#pragma unroll
+  for (int ps = 0; ps < 2 * TM; ++ps) {
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) s += acc[i][j][e];
-  out[(long)blockIdx.x * (WAVES * 64) + threadIdx.x] = s;
+      for (int e = 0; e < 8; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * fh, col = j * 32 + frow;
+        *reinterpret_cast<float*>(park + row * ROWB + (((col >> 2) ^ (row & 7)) << 4) + (col & 3) * 4) = acc[ps >> 1][j][(ps & 1) * 8 + e];
+      }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+      const int id = lane + 64 * t, row = id / (4 * TN), g = id - row * (4 * TN);
+      const float4 lo = *reinterpret_cast<const float4*>(park + row * ROWB + (((2 * g) ^ (row & 7)) << 4));
+      const float4 hi = *reinterpret_cast<const float4*>(park + row * ROWB + (((2 * g + 1) ^ (row & 7)) << 4));
+      const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      uint32_t pk[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) pk[u] = (__float_as_uint(v[2 * u]) >> 16) | (__float_as_uint(v[2 * u + 1]) & 0xffff0000u);
+      const long mr = ps * 16 + row;
+      if (m0 + wr * (BM / WM) + mr < M && n0 + wc * (BN / WN) + g * 8 < N)
+        *reinterpret_cast<uint4*>(cblk + mr * N + g * 8) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, int WGPC>
-static void run(const char* what, const uint16_t* A, const uint16_t* B, float* out, int M, int N, int K) {
+template <int BM, int BN, int WM, int WN, int STAGES, int WGPC, int EPI = 0>
+static void run(const char* what, const uint16_t* A, const uint16_t* B, float* out, int M, int N, int K, uint16_t* C = nullptr) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const size_t lds = (size_t)STAGES * (BM + BN) * 64;
-  auto kern = tile_kloop<BM, BN, WM, WN, STAGES, WGPC>;
+  auto kern = tile_kloop<BM, BN, WM, WN, STAGES, WGPC, EPI>;
   if (lds > 64 * 1024) CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
   const dim3 grid(tiles_m * tiles_n), block(WM * WN * 64);
-  for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(kern, grid, block, lds, 0, A, B, out, M, N, K, tiles_n);
+  for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(kern, grid, block, lds, 0, A, B, out, C, M, N, K, tiles_n);
   CK(hipDeviceSynchronize());
   float best = 1e30f;
   for (int r = 0; r < 7; ++r) {
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL(kern, grid, block, lds, 0, A, B, out, M, N, K, tiles_n);
+    hipLaunchKernelGGL(kern, grid, block, lds, 0, A, B, out, C, M, N, K, tiles_n);
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     float ms;
@@ -155,6 +192,8 @@ int main() {
   CK(hipMalloc(&A, na * 2));
   CK(hipMalloc(&B, nb * 2));
   CK(hipMalloc(&out, (size_t)64 << 20));
+  uint16_t* Cbuf;
+  CK(hipMalloc(&Cbuf, (size_t)M * 1536 * 2));
   {   // bf16 values around +-0.5 (0x3Exx / 0xBExx): finite, not constant
     uint16_t* h = (uint16_t*)malloc(na * 2);
     uint32_t s = 12345u;
@@ -176,6 +215,10 @@ int main() {
     run<128, 384, 2, 4, 2, 2>("128x384, 8 waves, 2 stages, 2 wg/CU", A, B, out, M, N, K);
     run<256, 256, 2, 4, 3, 1>("256x256, 8 waves, 3 stages, 1 wg/CU", A, B, out, M, N, K);
     run<256, 384, 4, 2, 3, 1>("256x384, 8 waves, 3 stages, 1 wg/CU", A, B, out, M, N, K);
+    // the same K loops followed by the kernels' epilogue skeleton (park, re-read by rows, 16-byte bf16 stores; no bias / GELU)
+    run<128, 128, 2, 2, 3, 3, 1>("128x128 ... + park + bf16 stores", A, B, out, M, N, K, Cbuf);
+    run<256, 128, 2, 2, 3, 2, 1>("256x128, 4 waves ... + stores", A, B, out, M, N, K, Cbuf);
+    run<128, 384, 2, 4, 2, 2, 1>("128x384, 8 waves, 2 st ... + stores", A, B, out, M, N, K, Cbuf);
   }
   return 0;
 }

@@ -184,6 +184,162 @@ static void run(const char* what, const uint16_t* A, const uint16_t* B, float* o
          tiles_m * tiles_n, lds >> 10, best * 1e3, fl / (best * 1e-3) / 1e12, into_lds / 1e9, into_lds / (best * 1e-3) / 1e12);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Wave-specialised persistent form: 256 x 128 tiles, one workgroup of 12 waves per CU.  Waves 0..7 (4 x 2, each 64 x 64) run ONE
+// continuous ring of K-steps across all the tiles of the workgroup and only ever issue loads; at the end of a tile they convert their
+// accumulators to bf16 and park them in a 64 KiB LDS buffer.  Waves 8..11 copy the parked tile of the PREVIOUS tile to memory, a slice
+// per K-step, in lockstep with the compute waves: every wave passes the same barriers, so the hand-over needs no flags, and the
+// stores (which share the in-order vmcnt with loads on gfx950) live on waves that never wait for a load.
+constexpr int SP_BM = 256, SP_BN = 128, SP_SLOT = (SP_BM + SP_BN) * 64, SP_PROW = 272;        // parked row: 256 B + 16 (bank spread)
+__global__ __launch_bounds__(768, 1) void spec_kloop(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, uint16_t* __restrict__ C,
+                                                      int M, int N, int K, int tiles_n, int ntiles, int mode) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const parkbuf = smem + 3 * SP_SLOT;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool is_compute = wv < 8;
+  const int nk = K / 32;
+  const int nw = gridDim.x, w = xcd_remap(blockIdx.x, nw);
+  const int my_tiles = (ntiles - w + nw - 1) / nw;                       // tiles w, w + nw, ...
+  const int total = my_tiles * nk;
+  auto tile_origin = [&](int t, long& m0, long& n0) {
+    const int tile = w + t * nw, tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    m0 = (long)tm * SP_BM;
+    n0 = (long)tn * SP_BN;
+  };
+  if (is_compute) {
+    const int wr = wv >> 1, wc = wv & 1, frow = lane & 31, fh = lane >> 5;
+    // staging: A 256 rows = 16 instructions (2 per compute wave), B 128 rows = 8 (1 per compute wave)
+    int it = 0, ikt = 0;                                                  // tile / K-step of the NEXT stage to request
+    long im0, in0;
+    tile_origin(0, im0, in0);
+    auto stage = [&](int slot) {
+      char* sa = smem + slot * SP_SLOT + wv * 2048;
+      char* sb = smem + slot * SP_SLOT + SP_BM * 64 + wv * 1024;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        int row = (wv * 2 + q) * 16 + (lane >> 2);
+        const int c = (lane & 3) ^ ((row >> 2) & 3);
+        row = im0 + row < M ? row : (int)(M - 1 - im0);
+        __builtin_amdgcn_global_load_lds((gbl_void*)(A + (im0 + row) * K + c * 8 + ikt * 32), (lds_void*)(sa + q * 1024), 16, 0, 0);
+      }
+      {
+        int row = wv * 16 + (lane >> 2);
+        const int c = (lane & 3) ^ ((row >> 2) & 3);
+        row = in0 + row < N ? row : (int)(N - 1 - in0);
+        __builtin_amdgcn_global_load_lds((gbl_void*)(B + (in0 + row) * K + c * 8 + ikt * 32), (lds_void*)sb, 16, 0, 0);
+      }
+      if (++ikt == nk) {
+        ikt = 0;
+        ++it;
+        if (it < my_tiles) tile_origin(it, im0, in0);
+      }
+    };
+    f32x16 acc[2][2];
+    int slot = 0, kt = 0;
+    if (total > 0) stage(0);
+    if (total > 1) stage(1);
+    for (int s = 0; s < total + nk; ++s) {                               // + nk: drain steps for the store waves' last tile
+      if (s < total) {
+        if (s + 2 <= total) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // fragment reads of the previous step, park writes of the previous tile
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (s >= total) continue;
+      if (s + 2 < total) stage(slot == 0 ? 2 : slot - 1);
+      if (kt == 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+      }
+      const char* sa = smem + slot * SP_SLOT;
+      const char* sb = sa + SP_BM * 64;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 af[2], bfr[2];
+        const int kc = 2 * ks + fh;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int ra = wr * 64 + i * 32 + frow;
+          af[i] = *reinterpret_cast<const bf16x8*>(sa + ra * 64 + ((kc ^ ((ra >> 2) & 3)) << 4));
+          const int rb = wc * 64 + i * 32 + frow;
+          bfr[i] = *reinterpret_cast<const bf16x8*>(sb + rb * 64 + ((kc ^ ((rb >> 2) & 3)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      }
+      slot = slot == 2 ? 0 : slot + 1;
+      if (++kt == nk) {                                                   // tile done: park it as bf16 (the store waves read the previous tile
+        kt = 0;
+        if (mode & 2) continue;                                           // (ablation: no parking)                                                           //  during this tile's K-steps and are past it by this step's barrier)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              const int row = wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh, col = wc * 64 + j * 32 + frow;
+              *reinterpret_cast<uint16_t*>(parkbuf + row * SP_PROW + col * 2) = (uint16_t)(__float_as_uint(acc[i][j][e]) >> 16);
+            }
+      }
+    }
+  } else {
+    // ---- store waves: slice (kt, sw) of the tile parked at the end of the previous tile's K-steps
+    const int sw = wv - 8;
+    for (int s = 0; s < total + nk; ++s) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (s < nk) continue;                                              // nothing parked during the first tile
+      const int t = s / nk - 1, kt = s - (t + 1) * nk;
+      long m0, n0;
+      tile_origin(t, m0, n0);
+      // 256 rows x 256 B = 64 chunks of 4 rows; 4 store waves x 2 chunks per step cover them in 8 steps
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int chunk = (kt * 2 + u) * 4 + sw;
+        if (chunk >= 64) continue;
+        const int row = chunk * 4 + (lane >> 4), piece = lane & 15;
+        const uint4 v = *reinterpret_cast<const uint4*>(parkbuf + row * SP_PROW + piece * 16);
+        if (m0 + row < M && n0 + piece * 8 < N && (!(mode & 1) || v.x == 0x12345678u)) *reinterpret_cast<uint4*>(C + (m0 + row) * N + n0 + piece * 8) = v;
+      }
+    }
+  }
+}
+
+static void run_spec(const uint16_t* A, const uint16_t* B, uint16_t* C, int M, int N, int K, int ncu, int mode = 0) {
+  const int tiles_m = (M + SP_BM - 1) / SP_BM, tiles_n = (N + SP_BN - 1) / SP_BN, ntiles = tiles_m * tiles_n;
+  if (K / 32 < 8) { printf("  (specialised form needs >= 8 K-steps)\n"); return; }
+  const size_t lds = 3 * (size_t)SP_SLOT + (size_t)SP_BM * SP_PROW;
+  CK(hipFuncSetAttribute((const void*)spec_kloop, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  const int grid = ncu < ntiles ? ncu : ntiles;
+  for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(spec_kloop, dim3(grid), dim3(768), lds, 0, A, B, C, M, N, K, tiles_n, ntiles, mode);
+  CK(hipDeviceSynchronize());
+  float best = 1e30f;
+  for (int r = 0; r < 7; ++r) {
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(spec_kloop, dim3(grid), dim3(768), lds, 0, A, B, C, M, N, K, tiles_n, ntiles, mode);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    best = ms < best ? ms : best;
+  }
+  const double fl = 2.0 * M * N * K;
+  printf("  %-34s %4d x %-4d tiles %5d  LDS %3zu KiB  %7.1f us  %6.0f TFLOP/s   (stores included)\n",
+         mode == 0 ? "256x128 persistent, 8 + 4 waves" : mode == 1 ? "  ... without the global stores" : "  ... without stores and parking", SP_BM, SP_BN, ntiles, lds >> 10, best * 1e3, fl / (best * 1e-3) / 1e12);
+}
+
 int main() {
   const int M = 512 * 201;
   uint16_t *A, *B;
@@ -219,6 +375,9 @@ int main() {
     run<128, 128, 2, 2, 3, 3, 1>("128x128 ... + park + bf16 stores", A, B, out, M, N, K, Cbuf);
     run<256, 128, 2, 2, 3, 2, 1>("256x128, 4 waves ... + stores", A, B, out, M, N, K, Cbuf);
     run<128, 384, 2, 4, 2, 2, 1>("128x384, 8 waves, 2 st ... + stores", A, B, out, M, N, K, Cbuf);
+    run_spec(A, B, Cbuf, M, N, K, 256);
+    run_spec(A, B, Cbuf, M, N, K, 256, 1);
+    run_spec(A, B, Cbuf, M, N, K, 256, 3);
   }
   return 0;
 }

@@ -43,6 +43,19 @@ typedef __attribute__((address_space(3))) void ar_lds_void;
 typedef __attribute__((address_space(1))) const void ar_gbl_void;
 typedef unsigned ar_u32x4 __attribute__((ext_vector_type(4)));      // (a native vector: HIP's uint4 is a struct, which inline asm cannot tie)
 
+typedef float ar_f32x4 __attribute__((ext_vector_type(4)));
+
+// Output stores are NON-TEMPORAL (global_store ... nt): results are 79-316 MB tensors that nobody re-reads before they have left the
+// 32 MB of L2, while the operand slices of the tiles still running are re-read from L2 3 to 12 times.  With ordinary stores the
+// output stream evicts them: tools/tile_probe.hip, K loop + output skeleton, qkv 156.8 -> 129.6 us, fc1 200.1 -> 153.5 us with `nt`;
+// this kernel: fc1 268 -> 218 us, teacher fc1 224 -> 197, GELU' product 222 -> 200, qkv 147 -> 143.
+// (a compile-time choice: written as a run-time branch the two stores are merged into one plain store and the hint is lost)
+template <bool NT, typename V>
+__device__ __forceinline__ void ar_store(char* dst, V v) {
+  if (NT) __builtin_nontemporal_store(v, reinterpret_cast<V*>(dst));
+  else *reinterpret_cast<V*>(dst) = v;
+}
+
 constexpr int AR_BK = 32, AR_BM = 128, AR_BN = 128;
 constexpr int AR_SETS = 6;                                             // register sets of the A prefetch (K-step mod 6)
 constexpr int AR_ATILE = AR_BM * AR_BK * 2, AR_BTILE = AR_BN * AR_BK * 2, AR_SLOT = AR_ATILE + AR_BTILE;
@@ -55,7 +68,7 @@ __device__ __forceinline__ int ar_xcd_remap(int bid, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <int OUT_DT, int ACT, bool RES>
+template <int OUT_DT, int ACT, bool RES, bool NT>
 __global__ __launch_bounds__(256, 3) void gemm_bf16_nt_areg(GemmParams p, int ntiles, int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -324,7 +337,7 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16_nt_areg(GemmParams p, int nt
             pa[2 * h] = (unsigned)f32_to_bf16(a[0]) | ((unsigned)f32_to_bf16(a[1]) << 16);
             pa[2 * h + 1] = (unsigned)f32_to_bf16(a[2]) | ((unsigned)f32_to_bf16(a[3]) << 16);
           } else if (p.aux) {
-            *reinterpret_cast<float4*>(ablk + ai + 16 * h) = make_float4(a[0], a[1], a[2], a[3]);
+            ar_store<NT>(ablk + ai + 16 * h, ar_f32x4{a[0], a[1], a[2], a[3]});
           }
         }
         if (ACT == AR_DGELU) {
@@ -354,12 +367,12 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16_nt_areg(GemmParams p, int nt
           pv[2 * h] = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
           pv[2 * h + 1] = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
         } else {
-          *reinterpret_cast<float4*>(cblk + ci + 16 * h) = make_float4(v[0], v[1], v[2], v[3]);
+          ar_store<NT>(cblk + ci + 16 * h, ar_f32x4{v[0], v[1], v[2], v[3]});
         }
       }
       if (OUT_DT == DINOX_BF16) {
-        if (ACT == AR_GELU && p.aux) *reinterpret_cast<ar_u32x4*>(ablk + ai) = ar_u32x4{pa[0], pa[1], pa[2], pa[3]};
-        *reinterpret_cast<ar_u32x4*>(cblk + ci) = ar_u32x4{pv[0], pv[1], pv[2], pv[3]};
+        if (ACT == AR_GELU && p.aux) ar_store<NT>(ablk + ai, ar_u32x4{pa[0], pa[1], pa[2], pa[3]});
+        ar_store<NT>(cblk + ci, ar_u32x4{pv[0], pv[1], pv[2], pv[3]});
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -384,7 +397,13 @@ bool gemm_bf16_nt_areg_ok(const GemmParams& p) {
 
 template <int OUT_DT, int ACT, bool RES>
 static void ar_launch(const GemmParams& p, unsigned ntile, int tiles_n, size_t lds, hipStream_t st) {
-  hipLaunchKernelGGL((gemm_bf16_nt_areg<OUT_DT, ACT, RES>), dim3(ntile), dim3(256), lds, st, p, (int)ntile, tiles_n);
+  // non-temporal output stores (see ar_store).  Same box, back to back: fc1 + side tensor 268 -> 218 us, teacher fc1 224 -> 197,
+  // GELU' product 222 -> 200, qkv 147 -> 143, proj (fp32 residual stream, 3 column tiles) 93 -> 93.  DINOX_NT_STORES=0 restores
+  // ordinary stores for A/B runs.
+  const char* e = getenv("DINOX_NT_STORES");
+  const int nt = e ? atoi(e) : 1;
+  if (nt) hipLaunchKernelGGL((gemm_bf16_nt_areg<OUT_DT, ACT, RES, true>), dim3(ntile), dim3(256), lds, st, p, (int)ntile, tiles_n);
+  else hipLaunchKernelGGL((gemm_bf16_nt_areg<OUT_DT, ACT, RES, false>), dim3(ntile), dim3(256), lds, st, p, (int)ntile, tiles_n);
 }
 
 int launch_gemm_bf16_nt_areg(const GemmParams& p, hipStream_t st) {

@@ -150,7 +150,12 @@ __global__ __launch_bounds__(WM * WN * 64, WGPC) void tile_kloop(const uint16_t*
       for (int u = 0; u < 4; ++u) pk[u] = (__float_as_uint(v[2 * u]) >> 16) | (__float_as_uint(v[2 * u + 1]) & 0xffff0000u);
       const long mr = ps * 16 + row;
       if (m0 + wr * (BM / WM) + mr < M && n0 + wc * (BN / WN) + g * 8 < N)
-        *reinterpret_cast<uint4*>(cblk + mr * N + g * 8) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+      {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 pv = {pk[0], pk[1], pk[2], pk[3]};
+        if (EPI == 2) __builtin_nontemporal_store(pv, reinterpret_cast<u32x4*>(cblk + mr * N + g * 8));
+        else *reinterpret_cast<u32x4*>(cblk + mr * N + g * 8) = pv;
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -373,6 +378,7 @@ int main() {
     run<256, 384, 4, 2, 3, 1>("256x384, 8 waves, 3 stages, 1 wg/CU", A, B, out, M, N, K);
     // the same K loops followed by the kernels' epilogue skeleton (park, re-read by rows, 16-byte bf16 stores; no bias / GELU)
     run<128, 128, 2, 2, 3, 3, 1>("128x128 ... + park + bf16 stores", A, B, out, M, N, K, Cbuf);
+    run<128, 128, 2, 2, 3, 3, 2>("128x128 ... + non-temporal stores", A, B, out, M, N, K, Cbuf);
     run<256, 128, 2, 2, 3, 2, 1>("256x128, 4 waves ... + stores", A, B, out, M, N, K, Cbuf);
     run<128, 384, 2, 4, 2, 2, 1>("128x384, 8 waves, 2 st ... + stores", A, B, out, M, N, K, Cbuf);
     run_spec(A, B, Cbuf, M, N, K, 256);

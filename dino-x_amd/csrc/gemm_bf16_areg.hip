@@ -400,8 +400,10 @@ static void ar_launch(const GemmParams& p, unsigned ntile, int tiles_n, size_t l
   // non-temporal output stores (see ar_store).  Same box, back to back: fc1 + side tensor 268 -> 218 us, teacher fc1 224 -> 197,
   // GELU' product 222 -> 200, qkv 147 -> 143, proj (fp32 residual stream, 3 column tiles) 93 -> 93.  DINOX_NT_STORES=0 restores
   // ordinary stores for A/B runs.
+  // Only for bf16 outputs: the fp32 outputs are the residual stream, which the following LayerNorm reads straight back (neutral on
+  // proj here, +9 % on the K = 1536 fc2 product when tried in gemm_bf16_nt_glds, whose bf16 products gain 1-2 %: not adopted there).
   const char* e = getenv("DINOX_NT_STORES");
-  const int nt = e ? atoi(e) : 1;
+  const int nt = e ? atoi(e) : (OUT_DT == DINOX_BF16 ? 1 : 0);
   if (nt) hipLaunchKernelGGL((gemm_bf16_nt_areg<OUT_DT, ACT, RES, true>), dim3(ntile), dim3(256), lds, st, p, (int)ntile, tiles_n);
   else hipLaunchKernelGGL((gemm_bf16_nt_areg<OUT_DT, ACT, RES, false>), dim3(ntile), dim3(256), lds, st, p, (int)ntile, tiles_n);
 }

@@ -452,8 +452,8 @@ const char* gemm_bf16_variant(const GemmParams& p) {
     const int64_t maxk = e ? atoll(e) : 576;
     static const bool no_areg = getenv("DINOX_NT_NO_AREG") != nullptr;
     // DINOX_NT_WIDE=1: wide outputs (N = 3D, 4D: qkv, fc1, the GELU' product) at short K on 128 x 384 tiles (gemm_bf16_wide.hip).
-    // Opt-in: its K loop is 17-23 % shorter (tools/tile_probe.hip) but the whole kernel measures qkv 146 vs 147 us, fc1 287 vs 279,
-    // teacher fc1 231 vs 230, GELU' product 302 vs 221 (no prefetch of the side tensor yet) against the register-prefetch kernel.
+    // Opt-in: its K loop is 17-23 % shorter (tools/tile_probe.hip) but the whole kernel measures qkv 153 vs 144 us, fc1 231 vs 218,
+    // teacher fc1 197 vs 202, GELU' product 274 vs 202 (no prefetch of the side tensor yet) against the register-prefetch kernel.
     const char* we = getenv("DINOX_NT_WIDE");
     if (we && atoi(we) != 0 && p.K <= 576 && gemm_bf16_nt_wide_ok(p)) return "gemm_bf16_nt_wide";
     return !no_areg && p.K <= maxk && gemm_bf16_nt_areg_ok(p) ? "gemm_bf16_nt_areg" : "gemm_bf16_nt_glds";

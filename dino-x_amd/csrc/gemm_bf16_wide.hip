@@ -8,8 +8,8 @@
 // operand is re-read from L2 three (four) times instead of nine (twelve), and sixteen waves per CU hide the one-step prefetch.
 //
 // STATUS: correct (tests/test_gpu_parity.py::test_gemm_nt_wide) and OPT-IN (DINOX_NT_WIDE=1).  The shorter K loop does not carry
-// over to the whole kernel yet: qkv 146 vs 147 us, fc1 287 vs 279 us, teacher fc1 231 vs 230 us, GELU' product 302 vs 221 us against
-// gemm_bf16_nt_areg.  What is left after the K loop (~50 us for qkv against ~32 us there) is the epilogue: four passes of park /
+// over to the whole kernel yet: with non-temporal stores on both sides qkv 153 vs 144 us, fc1 231 vs 218 us, teacher fc1 197 vs 202 us,
+// GELU' product 274 vs 202 us against gemm_bf16_nt_areg.  What is left after the K loop (~50 us for qkv against ~32 us there) is the epilogue: four passes of park /
 // re-read per wave with two workgroups per CU, 7-9 spilled registers in the GELU forms at the 128-VGPR budget of four waves per
 // SIMD, and the GELU' side tensor read where it is used.  Kept as the starting point for that work.
 //
@@ -187,8 +187,9 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16_nt_wide(GemmParams p, int nt
         pv[2 * h] = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
         pv[2 * h + 1] = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
       }
-      if (ACT == GW_GELU && p.aux) *reinterpret_cast<gw_u32x4*>(ablk + ai) = gw_u32x4{pa[0], pa[1], pa[2], pa[3]};
-      *reinterpret_cast<gw_u32x4*>(cblk + ci) = gw_u32x4{pv[0], pv[1], pv[2], pv[3]};
+      // non-temporal: the output stream must not evict the operand slices the running tiles re-read from L2 (gemm_bf16_areg.hip)
+      if (ACT == GW_GELU && p.aux) __builtin_nontemporal_store(gw_u32x4{pa[0], pa[1], pa[2], pa[3]}, reinterpret_cast<gw_u32x4*>(ablk + ai));
+      __builtin_nontemporal_store(gw_u32x4{pv[0], pv[1], pv[2], pv[3]}, reinterpret_cast<gw_u32x4*>(cblk + ci));
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();

@@ -381,6 +381,8 @@ int main() {
     run<128, 128, 2, 2, 3, 3, 2>("128x128 ... + non-temporal stores", A, B, out, M, N, K, Cbuf);
     run<256, 128, 2, 2, 3, 2, 1>("256x128, 4 waves ... + stores", A, B, out, M, N, K, Cbuf);
     run<128, 384, 2, 4, 2, 2, 1>("128x384, 8 waves, 2 st ... + stores", A, B, out, M, N, K, Cbuf);
+    run<256, 128, 2, 2, 3, 2, 2>("256x128, 4 waves ... + nt stores", A, B, out, M, N, K, Cbuf);
+    run<128, 384, 2, 4, 2, 2, 2>("128x384, 8 waves ... + nt stores", A, B, out, M, N, K, Cbuf);
     run_spec(A, B, Cbuf, M, N, K, 256);
     run_spec(A, B, Cbuf, M, N, K, 256, 1);
     run_spec(A, B, Cbuf, M, N, K, 256, 3);

@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256, (GG_BM == 256 ? 2 : (GG_BK == 64 ? 2 : 3))) vo
             s16x8 pk;
 #pragma unroll
             for (int u = 0; u < 8; ++u) pk[u] = (short)f32_to_bf16(a[u]);
-            *reinterpret_cast<s16x8*>((bf16_t*)p.aux + ai) = pk;
+            __builtin_nontemporal_store(pk, reinterpret_cast<s16x8*>((bf16_t*)p.aux + ai));   // (bf16 outputs: see gemm_bf16_areg.hip, ar_store)
           } else {
             *reinterpret_cast<float4*>((float*)p.aux + ai) = make_float4(a[0], a[1], a[2], a[3]);
             *reinterpret_cast<float4*>((float*)p.aux + ai + 4) = make_float4(a[4], a[5], a[6], a[7]);
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256, (GG_BM == 256 ? 2 : (GG_BK == 64 ? 2 : 3))) vo
         s16x8 pk;
 #pragma unroll
         for (int u = 0; u < 8; ++u) pk[u] = (short)f32_to_bf16(v[u]);
-        *reinterpret_cast<s16x8*>((bf16_t*)p.C + ci) = pk;
+        __builtin_nontemporal_store(pk, reinterpret_cast<s16x8*>((bf16_t*)p.C + ci));
       } else {
         *reinterpret_cast<float4*>((float*)p.C + ci) = make_float4(v[0], v[1], v[2], v[3]);
         *reinterpret_cast<float4*>((float*)p.C + ci + 4) = make_float4(v[4], v[5], v[6], v[7]);

@@ -181,7 +181,14 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16_nt_areg(GemmParams p, int nt
       if (PF_AUX) {
         const unsigned ai = (unsigned)((mr * (int)p.ldaux + col) * ESZ);
 #pragma unroll
-        for (int h = 0; h < AUXV; ++h) pf_aux[it][h] = *reinterpret_cast<const float4*>(ablk_l + ai + 16 * h);
+        for (int h = 0; h < AUXV; ++h) {
+          if (NT) {                                              // read once: streamed past L2 like the outputs
+            const ar_f32x4 xv = __builtin_nontemporal_load(reinterpret_cast<const ar_f32x4*>(ablk_l + ai + 16 * h));
+            pf_aux[it][h] = make_float4(xv[0], xv[1], xv[2], xv[3]);
+          } else {
+            pf_aux[it][h] = *reinterpret_cast<const float4*>(ablk_l + ai + 16 * h);
+          }
+        }
       }
       if (RES) {
         const unsigned ri = (unsigned)((mr * (int)p.ldr + col) * 4);

@@ -410,7 +410,12 @@ static void ar_launch(const GemmParams& p, unsigned ntile, int tiles_n, size_t l
   // Only for bf16 outputs: the fp32 outputs are the residual stream, which the following LayerNorm reads straight back (neutral on
   // proj here, +9 % on the K = 1536 fc2 product when tried in gemm_bf16_nt_glds, whose bf16 products gain 1-2 %: not adopted there).
   const char* e = getenv("DINOX_NT_STORES");
-  const int nt = e ? atoi(e) : (OUT_DT == DINOX_BF16 ? 1 : 0);
+  int nt = e ? atoi(e) : (OUT_DT == DINOX_BF16 ? 1 : 0);
+  // (A/B values: 2 = only outputs of 10 or more column tiles, 3 = only narrower ones.  Whole step on one box: off 44.40 ms, 3: 44.05,
+  //  2: 43.34, all bf16 outputs: 43.45.  LayerNorm outputs are the opposite case: stored non-temporally the step LOSES 1.1 ms, the
+  //  79 MB they write are still in the last-level cache when the next GEMM reads them.)
+  if (nt == 2) nt = OUT_DT == DINOX_BF16 && tiles_n >= 10;
+  if (nt == 3) nt = OUT_DT == DINOX_BF16 && tiles_n < 10;
   if (nt) hipLaunchKernelGGL((gemm_bf16_nt_areg<OUT_DT, ACT, RES, true>), dim3(ntile), dim3(256), lds, st, p, (int)ntile, tiles_n);
   else hipLaunchKernelGGL((gemm_bf16_nt_areg<OUT_DT, ACT, RES, false>), dim3(ntile), dim3(256), lds, st, p, (int)ntile, tiles_n);
 }

@@ -1141,6 +1141,27 @@ def test_gemm_nt_wide(dx, M, N, K, monkeypatch):
     assert rel_l2(d2.float(), ref * gelu_grad(pre_aux.float().double().cpu())) < 3e-3
 
 
+def test_gemm_nt_store_policy_is_only_a_hint(dx, monkeypatch):
+    """The register-prefetch kernel writes its bf16 outputs with non-temporal stores (DINOX_NT_STORES, csrc/gemm_bf16_areg.hip): a cache
+    hint, so results must be bit-identical with it off, for the plain, GELU (+ side tensor) and GELU' forms."""
+    ops, _ = dx
+    g = torch.Generator(device=DEV).manual_seed(3)
+    M, N, K = 128 * 37 + 11, 1536, 384
+    A = (torch.randn(M, K, device=DEV, generator=g) * 0.5).bfloat16()
+    B = (torch.randn(N, K, device=DEV, generator=g) * 0.3).bfloat16()
+    bias = torch.randn(N, device=DEV, generator=g)
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("DINOX_NT_STORES", mode)
+        aux = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        c = ops.gemm(A, B, bias=bias)
+        act = ops.gemm(A, B, bias=bias, gelu=True, aux=aux, auxgrad=True)
+        d = ops.gemm(A, B, dgelu=True, aux=aux, auxgrad=True)
+        outs[mode] = (c, act, aux, d)
+    for x, y in zip(outs["0"], outs["1"]):
+        assert torch.equal(x, y)
+
+
 @pytest.mark.parametrize("N,K,res", [(1152, 384, False), (384, 1536, True)])
 def test_gemm_nt_areg_full_size_repeatable(dx, N, K, res, monkeypatch):
     """BASELINE size (M = 512 views x 201 tokens; the qkv product and the fc2 product with its fp32 residual) through the

@@ -320,8 +320,15 @@ __global__ __launch_bounds__(512) void attn_fwd_bf16_persist(const bf16_t* __res
     load_row_frags(f, base_of(pr) + (int64_t)qrow * rs, lane);
   };
 
-  bf16x8 qnext[4];
-  q_frags(qnext, pair, wv);                 // prefetched one pair ahead, together with that pair's images
+  // The wave's first query block of a pair does not come by per-lane row loads (64 lanes x 16 B from 32 different rows per
+  // instruction: 32 tag look-ups each; the address unit of this kernel was stalled by the cache 23 % of the time) but by LDS-DMA, as a
+  // 32-row image in the wave's output staging area -- free between the deferred store at the top of an iteration and the next one
+  // -- one pair ahead, and is read from there as fragments at the top of its iteration.
+  auto q_dma = [&](int pr) {
+    const int q0w = wv * 32;
+    dma_image(st_scratch, base_of(pr) + (int64_t)q0w * rs, rs, N - q0w, 32, 0, 1, lane);
+  };
+  q_dma(pair);
   issue(pair, 0);
   // Output stores are DEFERRED by one pair: the tile a wave finishes in iteration i is stored at the top of iteration i + 1, after
   // that iteration's wait and barrier.  vmcnt counts stores as well as loads, so with the stores at the end of an iteration the
@@ -341,25 +348,22 @@ __global__ __launch_bounds__(512) void attn_fwd_bf16_persist(const bf16_t* __res
   // front of the first MFMA of every iteration -- which waits for the NEXT pair's images, requested a moment earlier.
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   {
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qnext[ks]));
     const float seen = *reinterpret_cast<const volatile float*>(smem + lane * 4);
     asm volatile("" ::"v"(seen));
   }
   for (int it = 0; pair < npairs; pair += gridDim.x, ++it) {
     const int buf = it & 1;
-    bf16x8 qf[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = qnext[ks];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my DMA pieces (and Q fragments) for this pair have landed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my DMA pieces (images and Q block) for this pair have landed
     __builtin_amdgcn_s_barrier();                         // everyone's pieces landed; everyone is done with the other buffer
     __builtin_amdgcn_sched_barrier(0);
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(st_scratch + img_off(lane & 31, 2 * ks + hl));
     const int nxt = pair + gridDim.x;
-    if (nxt < npairs) {
-      q_frags(qnext, nxt, wv);
-      issue(nxt, buf ^ 1);
-    }
+    if (nxt < npairs) issue(nxt, buf ^ 1);
     if (it > 0) store_pending();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the staging area's reads (fragments above, the store's re-reads) have returned
+    if (nxt < npairs) q_dma(nxt);
     const char* kimg = smem + (2 * buf) * img_bytes;
     const char* vimg = kimg + img_bytes;
     const int b = pair / heads, hh = pair % heads;

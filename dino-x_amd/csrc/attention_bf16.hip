@@ -291,7 +291,7 @@ __device__ __forceinline__ void dma_image(char* __restrict__ img, const bf16_t* 
 
 // One workgroup per CU walks (batch, head) pairs.  K and V images are double-buffered and filled by LDS-DMA for pair i+1
 // while the MFMAs of pair i run, so HBM latency and the image fill never sit on the critical path (the one-pair-per-
-// workgroup kernel spends about half its time filling LDS with nothing to overlap).  Wave w owns query blocks w, w+nw, ...
+// workgroup kernel spends about half its time filling LDS with nothing to overlap).  Wave w owns query block w (nblk <= nw).
 template <int NKT>   // NKT > 0: one pass, all NKT score tiles stay in registers (16*NKT VGPRs);  NKT == 0: two passes, any nkt
 __global__ __launch_bounds__(512) void attn_fwd_bf16_persist(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
                                                              float* __restrict__ lse, int N, int heads, int nkt, float sc,
@@ -313,11 +313,6 @@ __global__ __launch_bounds__(512) void attn_fwd_bf16_persist(const bf16_t* __res
     const bf16_t* base = base_of(pr);
     dma_image(smem + (2 * buf) * img_bytes, base + C, rs, N, npad, wv, nw, lane);
     dma_image(smem + (2 * buf + 1) * img_bytes, base + 2 * C, rs, N, npad, wv, nw, lane);
-  };
-  auto q_frags = [&](bf16x8 (&f)[4], int pr, int qb) {
-    int qrow = qb * 32 + (lane & 31);
-    qrow = qrow < N ? qrow : N - 1;
-    load_row_frags(f, base_of(pr) + (int64_t)qrow * rs, lane);
   };
 
   // The wave's first query block of a pair does not come by per-lane row loads (64 lanes x 16 B from 32 different rows per
@@ -371,7 +366,6 @@ __global__ __launch_bounds__(512) void attn_fwd_bf16_persist(const bf16_t* __res
     // iteration and is never live across another block's arithmetic): keep the normalised tile for the next iteration's stores.
     auto do_block = [&](int qb, auto defer_c) {
       constexpr bool DEFER = decltype(defer_c)::value;
-      if (qb != wv) q_frags(qf, pair, qb);               // more query blocks than waves (N > 256): fetched on demand
       const int q0 = qb * 32;
       // Key tile kt sits 4096 B after tile kt-1 in the image (32 rows = four 1-KiB row groups, swizzle terms unchanged), so
       // every fragment address is a per-lane constant plus kt*4096: computed once here, not per tile.
@@ -515,10 +509,9 @@ __global__ __launch_bounds__(512) void attn_fwd_bf16_persist(const bf16_t* __res
         store_block(o + (int64_t)b * N * C + hh * AT_D, C, q0, N, oacc[0], oacc[1], st_scratch, lane);
       }
     };
-    int qb = wv;
-    if constexpr (NKT == 0)                                                    // NKT > 0: one wave per query block (N <= 224)
-      for (; (qb + nw) * 32 < N; qb += nw) do_block(qb, std::false_type{});    // more query blocks than waves (N > 256 only)
-    do_block(qb, std::true_type{});
+    // One query block per wave: the launcher guarantees nblk <= nw (its LDS budget admits at most 7 blocks).  A wave walking
+    // several blocks would store through st_scratch while q_dma(nxt) streams the next pair's Q block into it.
+    do_block(wv, std::true_type{});
   }
   store_pending();
 }
@@ -717,7 +710,7 @@ int launch_attention_bf16_fwd(const void* qkv, void* o, float* lse, int B, int N
     const int nw = nblk < 8 ? nblk : 8;
     const size_t lds = (size_t)4 * nblk * 32 * 128 + 8 * 32 * sizeof(float) + 8 * (size_t)ST_BYTES;     // images, 1/rowsum, output staging
     static const bool off = getenv("DINOX_ATTN_NO_PERSIST") != nullptr;
-    if (lds <= 160 * 1024 && !off) {
+    if (lds <= 160 * 1024 && !off && nblk <= nw) {          // one query block per wave (the kernel relies on it)
       const int npairs = B * heads;
       const int nwgp = npairs < 256 ? npairs : 256;                 // one resident workgroup per CU
 #define PFWD(NKT)                                                                                                                  \
@@ -726,7 +719,7 @@ int launch_attention_bf16_fwd(const void* qkv, void* o, float* lse, int B, int N
     hipLaunchKernelGGL((attn_fwd_bf16_persist<NKT>), dim3(nwgp), dim3(nw * 64), lds, st, (const bf16_t*)qkv, (bf16_t*)o, lse, N,    \
                        heads, nblk, sc, npairs);                                                                                   \
   } while (0)
-      if (nblk == 7) PFWD(7); else if (nblk == 1) PFWD(1); else if (nblk == 2) PFWD(2); else PFWD(0);   // 8 tiles would spill: two-pass form
+      if (nblk == 7) PFWD(7); else if (nblk == 1) PFWD(1); else if (nblk == 2) PFWD(2); else PFWD(0);   // 3..6 blocks: two-pass form
 #undef PFWD
       return check_launch("attention_bf16_fwd_persist");
     }

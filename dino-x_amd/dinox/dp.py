@@ -105,6 +105,7 @@ class GradBucketer:
                 hi = None
         self._seen: set = set()
         self.active = True          # False on all but the last micro-batch of a gradient-accumulation group
+        self.fired_in_backward = 0  # buckets of the last step launched from grad_ready (i.e. overlapped), not by finish()
         self._hooks = []
         if self.exchange:
             for i, p in enumerate(params):
@@ -118,6 +119,7 @@ class GradBucketer:
 
     def arm(self) -> None:
         self._seen = set()
+        self.fired_in_backward = 0
         for b in self.buckets:
             b.pending = b.n_params
             b.work = None
@@ -129,6 +131,7 @@ class GradBucketer:
         b = self.buckets[self.bucket_of[i]]
         b.pending -= 1
         if b.pending == 0 and self.exchange and self.active:
+            self.fired_in_backward += 1
             b.work = dist.all_reduce(self.flat[b.lo:b.hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def finish(self) -> None:

@@ -130,14 +130,14 @@ class TrainEngine:
         last = (self.step_count + 1) % self.accum == 0
         if first:
             self.flat_g.zero_()
-        ops._UNFOLD_CACHE.clear()    # the unfolded batch is shared by student and teacher WITHIN a step, never carried across steps
         self.bucketer.active = last
         self.bucketer.arm()
         if ops.grad_sink.owner is not self:      # weight gradients accumulate straight into flat_g (ops._GradSink)
             ops.grad_sink.register(self, self.params, self.bucketer.grad_ready if self.bucketer.exchange else None)
             ops.weight_cache.shadows = self.shadows
         ops.grad_sink.uses.clear()
-        with ops.compute_dtype(self.compute_dtype):
+        # (the unfolded batch is shared by student and teacher WITHIN this scope, never carried across steps)
+        with ops.compute_dtype(self.compute_dtype), ops.unfold_share():
             main = torch.cuda.current_stream()
             # opt-in (DINOX_SIDE_STREAM=1): +1.3 % measured, but concurrent chains blur per-kernel timings, so bench/profiles keep it off
             side = self.side_stream if os.environ.get("DINOX_SIDE_STREAM") else None

@@ -15,6 +15,7 @@ import contextlib
 import ctypes as C
 import math
 import os
+import weakref
 from typing import Optional
 
 import torch
@@ -287,8 +288,13 @@ class ArenaShadow:
 
 class _WeightCache:
     """bf16 (and transposed bf16) copies of fp32 master weights.  Arena shadows registered by the training engine serve whole
-    models from one cast launch; anything else is cast per weight, keyed by storage + version so the student forward, its
-    backward and repeated teacher forwards of one step share one cast."""
+    models from one cast launch; anything else is cast per weight and cached so the student forward, its backward and repeated
+    teacher forwards of one step share one cast.
+
+    An entry is valid only for the very tensor OBJECT it was made from (held by weak reference and compared with ``is``) at
+    the version it had then: a freed model whose successor lands on the same addresses at version 0 (two ``load_model`` calls
+    in a row) can therefore never be served the old model's weights.  Writers that go around torch's version counter (the
+    ``dinox_adamw_ema`` kernel, any C-ABI caller writing through raw pointers) must call ``invalidate_weights()``."""
 
     def __init__(self) -> None:
         self.d: dict = {}
@@ -302,18 +308,26 @@ class _WeightCache:
             hit = sh.get(w, transposed)
             if hit is not None:
                 return hit
-        key = (w.data_ptr(), w._version, tuple(w.shape), transposed)
+        key = (id(w), transposed)
         hit = self.d.get(key)
-        if hit is None:
-            if len(self.d) > 4096:
-                self.d.clear()
-            w2 = w.detach().reshape(w.shape[0], -1)
-            hit = cast_transpose_bf16(w2) if transposed else cast_bf16(w2)
-            self.d[key] = hit
-        return hit
+        if hit is not None and hit[0]() is w and hit[1] == (w.data_ptr(), w._version, tuple(w.shape)):
+            return hit[2]
+        if len(self.d) > 4096:
+            self.d.clear()
+        w2 = w.detach().reshape(w.shape[0], -1)
+        val = cast_transpose_bf16(w2) if transposed else cast_bf16(w2)
+        d = self.d
+        self.d[key] = (weakref.ref(w, lambda _r, key=key, d=d: d.pop(key, None)), (w.data_ptr(), w._version, tuple(w.shape)), val)
+        return val
 
 
 weight_cache = _WeightCache()
+
+
+def invalidate_weights() -> None:
+    """Drop every cached bf16 weight image.  For callers that modify master weights through raw device pointers (the C ABI's
+    ``dinox_adamw_ema``, a custom optimiser): torch's version counter does not see such writes."""
+    weight_cache.clear()
 
 
 def weight_operand(w: Tensor, dt: torch.dtype, transposed=False) -> Tensor:
@@ -475,6 +489,7 @@ class _GradSink:
         self.uses: dict = {}
         self.on_ready = None
         self.owner = None
+        self.recomputing = 0        # > 0 while torch.utils.checkpoint re-runs a forward to rebuild saved tensors
 
     def register(self, owner, params, on_ready=None) -> None:
         self.slots = {p.data_ptr(): (i, p) for i, p in enumerate(params) if p.requires_grad and p.numel()}
@@ -496,7 +511,7 @@ class _GradSink:
 
     def use(self, *ws) -> None:
         """Forward passes that will back-propagate into these parameters announce themselves (DP only)."""
-        if self.on_ready is None:
+        if self.on_ready is None or self.recomputing:      # a recomputed forward adds no backward product of its own
             return
         for w in ws:
             slot = self.lookup(w)
@@ -513,6 +528,22 @@ class _GradSink:
 
 
 grad_sink = _GradSink()
+
+
+@contextlib.contextmanager
+def _recompute_scope():
+    grad_sink.recomputing += 1
+    try:
+        yield
+    finally:
+        grad_sink.recomputing -= 1
+
+
+def checkpoint_contexts():
+    """``context_fn`` for ``torch.utils.checkpoint.checkpoint(use_reentrant=False)``: (original forward, recomputation).
+    The recomputation runs every forward of the block a second time only to rebuild its saved tensors; marking it keeps the
+    gradient sink's use counts equal to the number of backward products, so data-parallel buckets still fire DURING backward."""
+    return contextlib.nullcontext(), _recompute_scope()
 
 
 def weight_grad(dy: Tensor, x: Tensor, w: Tensor, bias: Optional[Tensor], want_db: bool):
@@ -710,25 +741,58 @@ class AttentionCoreFn(torch.autograd.Function):
         return attention_bwd(do, qkv, o, lse, ctx.heads), None
 
 
-_UNFOLD_CACHE: dict = {}
+class _UnfoldShare:
+    """The student and the teacher of one training step see the same batch (scripts/phase5_big_run.py:1741-1743) and can share
+    its unfolded form.  Sharing is OPT-IN and scoped: only inside ``with unfold_share():`` (TrainEngine.step) is an unfolded
+    batch kept, the entry holds the input tensor itself (so its memory cannot be recycled under the entry) and is matched by
+    object identity + version; leaving the scope drops it.  A plain ``PatchViT.forward`` (encode(), eval loops) never looks here."""
+
+    def __init__(self) -> None:
+        self.depth = 0
+        self.entries: list = []
+
+    def find(self, x: Tensor, patch: int, dt: torch.dtype) -> Optional[Tensor]:
+        for (t, ver, p, d, u) in self.entries:
+            if t is x and ver == x._version and p == patch and d == dt:
+                return u
+        return None
+
+    def put(self, x: Tensor, patch: int, dt: torch.dtype, u: Tensor) -> None:
+        self.entries = [e for e in self.entries if e[0] is not x][-3:] + [(x, x._version, patch, dt, u)]
+
+
+_unfold_share = _UnfoldShare()
+
+
+@contextlib.contextmanager
+def unfold_share():
+    _unfold_share.depth += 1
+    try:
+        yield
+    finally:
+        _unfold_share.depth -= 1
+        if _unfold_share.depth == 0:
+            _unfold_share.entries = []
 
 
 def patch_unfold(x: Tensor, patch: int, dt: torch.dtype) -> Tensor:
-    """[V,3,H,W] fp32 -> [V*P, 3*p*p] in dt; cached per input batch so that student and teacher,
-    which see the same batch (scripts/phase5_big_run.py:1741-1743), share one unfold."""
+    """[V,3,H,W] fp32 -> [V*P, 3*p*p] in dt (shared between student and teacher inside ``unfold_share()`` only)."""
     _need_cuda(x)
+    sharing = _unfold_share.depth > 0
+    if sharing:
+        hit = _unfold_share.find(x, patch, dt)
+        if hit is not None:
+            return hit
+    x0 = x
     x = _c(x)
     if x.dtype != torch.float32:
         x = x.float()
-    key = (x.data_ptr(), x._version, tuple(x.shape), patch, dt)
-    hit = _UNFOLD_CACHE.get("k")
-    if hit is not None and hit[0] == key:
-        return hit[1]
     V, Cn, H, W = x.shape
     assert Cn == 3, "2.5D slice stacks have 3 channels"
     u = torch.empty((V * (H // patch) * (W // patch), 3 * patch * patch), dtype=dt, device=x.device)
     check(lib.dinox_patch_unfold(_p(x), _p(u), V, H, W, patch, _code(dt), _stream()), "dinox_patch_unfold")
-    _UNFOLD_CACHE["k"] = (key, u)
+    if sharing:
+        _unfold_share.put(x0, patch, dt, u)
     return u
 
 

@@ -338,6 +338,25 @@ class DiverseBatchSampler(torch.utils.data.Sampler):
             yield order[full:]
 
 
+class ShardedBatchSampler(torch.utils.data.Sampler):
+    """Data-parallel sharding of a batch sampler: ``inner`` yields GLOBAL batches (world x per-rank batch indices) from a
+    generator seeded identically on every rank, and rank r keeps the contiguous slice dp.shard_range gives it.  The union over
+    ranks is exactly the batch sequence a single process would draw at the global batch size: no sample is seen twice in an
+    epoch, and an epoch has the same length on every rank (so collectives stay matched)."""
+
+    def __init__(self, inner, rank: int, world: int):
+        self.inner, self.rank, self.world = inner, rank, world
+
+    def __len__(self):
+        return len(self.inner)
+
+    def __iter__(self):
+        from dinox.dp import shard_range
+        for global_batch in self.inner:
+            lo, hi = shard_range(len(global_batch), self.rank, self.world)
+            yield global_batch[lo:hi]
+
+
 def dino_collate(batch):
     views, spacings = zip(*batch)
     return [torch.stack([v[0] for v in views]), torch.stack([v[1] for v in views])], torch.stack(list(spacings))
@@ -445,7 +464,8 @@ def load_checkpoint(path: Path, student: nn.Module, teacher: nn.Module, eng: Tra
     path = Path(path)
     if not path.exists():
         raise FileNotFoundError(f"Checkpoint not found: {path}")
-    payload = torch.load(path, map_location="cpu", weights_only=False)     # own/trusted file: config + RNG blobs
+    from zoo.hub import read_checkpoint
+    payload = read_checkpoint(path, "cpu")          # restricted unpickler + allow-list for the NumPy RNG blob (zoo/hub.py)
     for key in ("student", "teacher"):
         if key in payload and needs_migration(payload[key]):
             warnings.warn(f"Migrating old-format {key} state dict keys to timm-style")
@@ -621,6 +641,7 @@ def main(argv=None) -> None:
         git_commit=git_commit, data_manifest_hash=data_hash)
     say(f"effective_batch_size={cfg.effective_batch_size * world} (batch={args.batch_size} × accum={args.accumulation_steps} × ranks={world})")
     _seed_all(args.train_seed)
+    local = local % torch.cuda.device_count()          # (rehearsals may put several gloo ranks on one GPU)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     say(f"device={device.type}")
@@ -677,7 +698,7 @@ def main(argv=None) -> None:
     if len(ds) < args.batch_size:
         say(f"⚠️  Dataset size ({len(ds)}) is smaller than batch size ({args.batch_size}). Reducing batch size to {len(ds)}.")
         args.batch_size = cfg.batch_size = len(ds)
-    gen = torch.Generator().manual_seed(args.train_seed + 1000 * rank)      # each rank draws its own shard order
+    gen = torch.Generator().manual_seed(args.train_seed)      # the SAME sample order on every rank; ranks keep disjoint slices of it
 
     def _worker_init(worker_id: int) -> None:
         _seed_all(args.train_seed + 1000 * rank + worker_id)
@@ -693,12 +714,17 @@ def main(argv=None) -> None:
         say("gpu_views=True")
     common = dict(num_workers=hw.num_workers, pin_memory=hw.pin_memory and not args.gpu_views, worker_init_fn=_worker_init,
                   collate_fn=collate_stacks if args.gpu_views else dino_collate, persistent_workers=hw.num_workers > 0)
+    if len(ds) < args.batch_size * world:
+        raise SystemExit(f"dataset size ({len(ds)}) is smaller than the global batch ({args.batch_size} x {world} ranks)")
     if args.diverse_batches:
-        sampler = DiverseBatchSampler(rows, batch_size=args.batch_size, drop_last=True, generator=gen)
-        dl = torch.utils.data.DataLoader(ds, batch_sampler=sampler, **common)
+        sampler = DiverseBatchSampler(rows, batch_size=args.batch_size * world, drop_last=True, generator=gen)
         say(f"diverse_batches=True batches_per_epoch={len(sampler)}")
     else:
-        dl = torch.utils.data.DataLoader(ds, batch_size=args.batch_size, shuffle=True, drop_last=True, generator=gen, **common)
+        sampler = torch.utils.data.BatchSampler(torch.utils.data.RandomSampler(ds, generator=gen), batch_size=args.batch_size * world,
+                                                drop_last=True)
+    if world > 1:
+        sampler = ShardedBatchSampler(sampler, rank, world)
+    dl = torch.utils.data.DataLoader(ds, batch_sampler=sampler, **common)
     it = iter(dl)
 
     # ---- model / engine
@@ -731,8 +757,17 @@ def main(argv=None) -> None:
     say("─" * 80)
     step = start_step - 1
     pending = None                      # (step, scalars) of the previous step, fetched one step late: no stall of the GPU queue
+    stop_every = 10                     # under DP the ranks agree on an interrupt only at these steps (one tiny all-reduce + sync)
     for step in range(start_step, int(max_steps)):
-        if stop.stop:
+        if world > 1:
+            if (step - start_step) % stop_every == 0:
+                flag = torch.tensor([1.0 if stop.stop else 0.0], device=device)
+                torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+                stop.agreed = bool(flag.item())
+            stopping = getattr(stop, "agreed", False)
+        else:
+            stopping = stop.stop
+        if stopping:
             say("interrupt=true")
             step -= 1
             break
@@ -753,7 +788,12 @@ def main(argv=None) -> None:
             batch = torch.cat(views, 0).to(device, non_blocking=True)
         sp2 = torch.cat([spacing, spacing], 0).to(device, non_blocking=True) if args.scale_aware else None
         out = eng.step(batch, sp2, loc, spl)
-        cur = (step, out["loss"], out["lr"])
+        loss_t = out["loss"]
+        if world > 1:                   # the logged loss (and the NaN guard on it) is the global-batch mean, identical on every rank
+            loss_t = loss_t.clone()
+            torch.distributed.all_reduce(loss_t, op=torch.distributed.ReduceOp.SUM)
+            loss_t = loss_t / world
+        cur = (step, loss_t, out["lr"])
         # the loss of step s is read back while step s+1 is already queued
         for (s_, loss_t, lr_) in ([pending] if pending is not None else []):
             loss_val = float(loss_t)

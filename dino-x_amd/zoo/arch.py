@@ -221,7 +221,7 @@ class PatchViT(nn.Module):
         t = ops.TokensFn.apply(x, self.patch_embed.weight, self.patch_embed.bias, self.cls_token, pos, regs, scale, self.patch)
         for blk in self.blocks:
             if self.use_grad_checkpoint and self.training:
-                t = torch.utils.checkpoint.checkpoint(blk, t, use_reentrant=False)
+                t = torch.utils.checkpoint.checkpoint(blk, t, use_reentrant=False, context_fn=ops.checkpoint_contexts)
             else:
                 t = blk(t)
         return self.norm(t, out_dtype=torch.float32)

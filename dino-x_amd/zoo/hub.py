@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import json
 import logging
+import os
 import pickle
 from pathlib import Path
 from typing import Any, Dict, Union
@@ -41,14 +42,38 @@ def _strip_prefix(sd: Dict[str, torch.Tensor], prefix: str) -> Dict[str, torch.T
     return {(k[n:] if k.startswith(prefix) else k): v for k, v in sd.items()}
 
 
-def _read_checkpoint(path: Path, device) -> Any:
+def _rng_blob_globals() -> list:
+    """The only non-tensor objects a training checkpoint of this path carries (reference scripts/phase5_big_run.py:1041-1057):
+    ``np.random.get_state()`` -- a tuple holding one uint32 ndarray -- beside plain python containers."""
+    import numpy as np
+    try:
+        from numpy._core.multiarray import _reconstruct
+    except ImportError:                                     # numpy < 2
+        from numpy.core.multiarray import _reconstruct
+    return [_reconstruct, np.ndarray, np.dtype, type(np.dtype(np.uint32)), type(np.dtype(np.float64)), type(np.dtype(np.int64))]
+
+
+def read_checkpoint(path: Path, device) -> Any:
+    """torch.load with the restricted (weights_only) unpickler; training checkpoints, whose RNG blob holds a NumPy array,
+    get an allow-list of exactly those NumPy globals.  Nothing else is ever unpickled unless the user opts in with
+    DINOX_ALLOW_PICKLE=1 (the reference itself loads these files with weights_only=False, zoo/hub.py:99)."""
     try:
         return torch.load(path, map_location=device, weights_only=True)
     except pickle.UnpicklingError:
-        # Reference training checkpoints carry Python/NumPy RNG blobs that the restricted unpickler
-        # refuses; they are the user's own files, exactly what the reference loads the same way.
-        log.warning("%s needs full unpickling (training checkpoint with RNG state)", path.name)
-        return torch.load(path, map_location=device, weights_only=False)
+        pass
+    try:
+        with torch.serialization.safe_globals(_rng_blob_globals()):
+            return torch.load(path, map_location=device, weights_only=True)
+    except pickle.UnpicklingError as e:
+        if os.environ.get("DINOX_ALLOW_PICKLE") == "1":
+            log.warning("%s: full unpickling (DINOX_ALLOW_PICKLE=1)", path.name)
+            return torch.load(path, map_location=device, weights_only=False)
+        raise pickle.UnpicklingError(
+            f"{path}: holds objects beyond tensors, containers and the NumPy RNG state; set DINOX_ALLOW_PICKLE=1 to load a "
+            f"file you trust with the full unpickler ({e})") from e
+
+
+_read_checkpoint = read_checkpoint
 
 
 def load_from_training_checkpoint(path: Union[str, Path], *, device: Union[str, torch.device] = "cpu",

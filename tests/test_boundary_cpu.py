@@ -206,3 +206,30 @@ def test_flatten_parameters_views_and_alignment():
     assert all(float(p.abs().sum()) == 0 for p in m.parameters())
     m.load_state_dict(before)                       # in-place copy keeps the views
     assert float(flat.abs().sum()) > 0
+
+
+def test_weight_cache_entries_die_with_their_tensor_and_unfold_sharing_is_scoped():
+    """caches keyed by a raw address served stale data when a new tensor reused a freed one's memory.  The bf16
+    weight cache now holds a weak reference to the very tensor object (entry gone when it is collected, `is`-checked on
+    lookup); the unfold cache exists only inside ``ops.unfold_share()`` and holds its input alive."""
+    import gc
+    from dinox import ops
+    wc = ops._WeightCache()
+    w = torch.nn.Parameter(torch.randn(4, 8))
+    sentinel = object()
+    key = (id(w), False)
+    import weakref
+    wc.d[key] = (weakref.ref(w, lambda _r, key=key, d=wc.d: d.pop(key, None)), (w.data_ptr(), w._version, tuple(w.shape)), sentinel)
+    assert wc.d[key][0]() is w
+    del w
+    gc.collect()
+    assert key not in wc.d                     # collected with its tensor: a successor at the same id/address cannot hit it
+    assert ops._unfold_share.depth == 0 and ops._unfold_share.entries == []
+    x = torch.randn(2, 3, 8, 8)
+    with ops.unfold_share():
+        ops._unfold_share.put(x, 4, torch.float32, sentinel)
+        assert ops._unfold_share.find(x, 4, torch.float32) is sentinel
+        assert ops._unfold_share.find(x.clone(), 4, torch.float32) is None          # identity, not address or shape
+        x.add_(1)
+        assert ops._unfold_share.find(x, 4, torch.float32) is None                  # version moved
+    assert ops._unfold_share.entries == []

@@ -170,3 +170,29 @@ def test_checkpoint_payload_roundtrip_and_adamw_format(cli, tmp_path):
     assert torch.equal(eng2.center, eng.center)
     with pytest.raises(FileNotFoundError):
         cli.load_checkpoint(tmp_path / "missing.pth", s2, t2, eng2, "cpu")
+
+
+def test_sharded_batch_sampler_partitions_global_batches(cli):
+    """Data parallel: every rank walks the SAME global batch sequence (shared seed) and keeps a disjoint contiguous slice; the
+    union over ranks is what one process would draw at the global batch, so an epoch sees no sample twice."""
+    n, B, world = 64, 4, 4
+    per_rank = []
+    for rank in range(world):
+        gen = torch.Generator().manual_seed(7)
+        inner = torch.utils.data.BatchSampler(torch.utils.data.RandomSampler(range(n), generator=gen), batch_size=B * world, drop_last=True)
+        per_rank.append(list(cli.ShardedBatchSampler(inner, rank, world)))
+    gen = torch.Generator().manual_seed(7)
+    single = list(torch.utils.data.BatchSampler(torch.utils.data.RandomSampler(range(n), generator=gen), batch_size=B * world, drop_last=True))
+    assert all(len(p) == len(single) == n // (B * world) for p in per_rank)
+    for i, g in enumerate(single):
+        assert sum((per_rank[r][i] for r in range(world)), []) == g
+    seen = [j for p in per_rank for b in p for j in b]
+    assert len(seen) == len(set(seen)) == n
+    # the series-diverse sampler shards the same way
+    rows = [cli.IndexRow(png_path=f"s{i % 8}/{i}.png", series_dir=f"s{i % 8}", slice_index=i // 8, encoding="u16") for i in range(n)]
+    shards = []
+    for rank in range(2):
+        inner = cli.DiverseBatchSampler(rows, batch_size=8, drop_last=True, generator=torch.Generator().manual_seed(3))
+        shards.append(list(cli.ShardedBatchSampler(inner, rank, 2)))
+    flat = [j for p in shards for b in p for j in b]
+    assert len(flat) == len(set(flat)) == n and all(len(b) == 4 for p in shards for b in p)

@@ -5,6 +5,9 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W          (one rank per GPU, RCCL)
 
+Started plainly with ``--gpus N`` (N > 1) it launches that second form itself: N fresh child processes, spawned BEFORE this
+process has made any GPU call, whose rank-0 line it relays (it never re-executes a process that touched the GPU).
+
 A "step" is one full optimiser step of the reference loop (scripts/phase5_big_run.py:1692-1802):
 student forward, teacher forward (no grad), DINO centring/sharpening CE + Gram-anchoring loss,
 backward, global grad-norm, AdamW, EMA teacher, centre update -- nothing skipped.
@@ -16,16 +19,24 @@ out_dim 8192, bf16 MFMA operands with fp32 accumulation / residual stream / loss
 Inputs are resident in HBM before the timed region.  Weak scaling: per-GPU batch fixed.
 
 Output: ONE JSON line on rank 0 (see the contract in the task description), with
-  roofline      the dominant kernel (the bf16 MFMA GEMM that carries most FLOPs): algorithmic FLOPs of its
-                launches / their summed duration, measured live with HIP events on the launch stream
-                over the timed region; "step" adds the whole-step figure of BASELINE.md section 2;
-  cpu_baseline  the CPU oracle's same training step timed on this box's host cores (rank 0, N=1 only).
+  roofline       the dominant kernel (the bf16 MFMA GEMM family that takes most of the step): algorithmic bytes / FLOPs of its
+                 launches / their summed duration, measured live with HIP events on the launch stream over the timed
+                 region; "step" adds the whole-step figure of BASELINE.md section 2;
+  step_ms_split  HIP-event time between the phase boundaries of the step (fwd_student, fwd_teacher, loss, bwd,
+                 comm_exposed, optimiser_tail), averaged over a few extra steps after the timed region
+                 (protocol of the reference's scripts/tune_throughput.py:640-668: one sync per step);
+  secondary      (N = 1 only) short measurements of the other single-GPU BASELINE configs: bs64_scale_off (configs[1]),
+                 multicrop_2g8l (the literal "2 global + 8 local crops" reading of configs[2]; an extension, the reference
+                 has two views), vit_large_bs128 (the per-GPU shape of configs[4]);
+  cpu_baseline   the CPU oracle's same training step timed on this box's host cores (rank 0, N=1 only).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,11 +45,9 @@ for _p in (ROOT, os.path.join(ROOT, "dino-x_amd")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
-import torch                      # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 PEAK_BF16_DENSE_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16 MFMA
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+PMC_FILE = "r02_pmc_traffic.json"  # profiles/: per-kernel HBM bytes from the rocprofv3 --pmc passes of this same command
 
 
 def fwd_flops_per_image(img=224, patch=16, dim=384, depth=12, out_dim=8192, regs=4, gram=True):
@@ -52,6 +61,7 @@ def fwd_flops_per_image(img=224, patch=16, dim=384, depth=12, out_dim=8192, regs
 def cpu_baseline(cfg_kw, out_dim, seconds_budget=25.0):
     """The oracle's training step (oracle/dinox_oracle.py: fp32 torch-CPU restatement of the reference
     loop) on a bounded sample of the same workload: same model, B=8 source samples per step."""
+    import torch
     from oracle import dinox_oracle as O
     from dinox.hostinfo import usable_cpus
     cores = usable_cpus()                                  # cpuset + cgroup quota, not os.cpu_count()
@@ -78,7 +88,7 @@ def cpu_baseline(cfg_kw, out_dim, seconds_budget=25.0):
             "sample": f"oracle train_step (fp32 torch CPU), ViT-S/16 224 scale-aware, B={B} samples/step, {n} timed steps after 1 warm-up"}
 
 
-def main() -> None:
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -87,19 +97,150 @@ def main() -> None:
     ap.add_argument("--fp32", action="store_true", help="parity mode (exact-fp32 MFMA) instead of bf16")
     ap.add_argument("--model", choices=["vit-small", "vit-large"], default="vit-small",
                     help="vit-small = BASELINE configs[2] (the metric's config); vit-large = configs[4] shape (not the headline metric)")
+    ap.add_argument("--no-scale-aware", action="store_true", help="configs[1]: scale embedding off")
     ap.add_argument("--local-crops", type=int, default=0,
                     help="multi-crop extension (not in the reference, whose loop has 2 global views): L extra student-only local views per sample")
     ap.add_argument("--local-size", type=int, default=96)
+    ap.add_argument("--graph", action="store_true", help="replay the step as one captured hipGraph (launch-bound small-batch regime)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short measurements of the other single-GPU configs")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket GEMM launches with HIP events")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+def launch_ranks(args) -> int:
+    """``python bench.py --gpus N`` outside torchrun: start N ranks as CHILD processes of a parent that has not touched the GPU
+    (``torch.cuda.device_count()`` does not initialise it on this image), relay their output, return their exit code."""
+    import torch
+    have = torch.cuda.device_count()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if have < args.gpus and env.get("DINOX_DIST_BACKEND") != "gloo":
+        print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible (set DINOX_DIST_BACKEND=gloo to rehearse several ranks per GPU)",
+              file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+class Workload:
+    """One configuration resident on the device: models, engine, synthetic batch."""
+
+    def __init__(self, dev, rank, *, model="vit-small", B=256, scale_aware=True, L=0, local_size=96, fp32=False, steps_hint=30, graph=False):
+        import torch
+        import zoo.arch as arch
+        from dinox.engine import StepHyperParams, TrainEngine
+        self.cfg_kw = dict(img_size=224, patch=16, dim=384, depth=12, heads=6, num_registers=4, scale_aware=scale_aware)
+        if model == "vit-large":
+            self.cfg_kw.update(dim=1024, depth=24, heads=16)
+        self.out_dim, self.B, self.L, self.local_size, self.model = 8192, B, L, local_size, model
+        torch.manual_seed(0)
+        student = arch.DinoStudentTeacher(arch.PatchViT(**self.cfg_kw), self.out_dim)
+        if scale_aware:      # exercise the scale branch: the reference zero-inits it, training moves it away from zero
+            torch.nn.init.xavier_uniform_(student.backbone.scale_embed.mlp[2].weight)
+        teacher = arch.DinoStudentTeacher(arch.PatchViT(**self.cfg_kw), self.out_dim)
+        teacher.load_state_dict(student.state_dict())
+        self.eng = TrainEngine(student.to(dev), teacher.to(dev), self.out_dim, StepHyperParams(max_steps=steps_hint + 10, warmup_steps=5),
+                               amp_dtype=None if fp32 else torch.bfloat16, **({"use_graph": True} if graph else {}))
+        g = torch.Generator().manual_seed(1234 + rank)       # per-rank shard of the synthetic global batch
+        self.batch = torch.randn(2 * B, 3, 224, 224, generator=g).to(dev)
+        sp = (torch.rand(B, 3, generator=g) * torch.tensor([0.52, 0.52, 4.375]) + torch.tensor([0.46, 0.46, 0.625]))
+        self.sp2 = torch.cat([sp, sp], 0).to(dev) if scale_aware else None
+        self.loc = torch.randn(L * B, 3, local_size, local_size, generator=g).to(dev) if L else None
+        self.spl = torch.cat([sp] * L, 0).to(dev) if (L and scale_aware) else None
+
+    def step(self):
+        return self.eng.step(self.batch, self.sp2, self.loc, self.spl)
+
+    def gflop_per_sample(self) -> float:
+        gf = 8.0 * fwd_flops_per_image(dim=self.cfg_kw["dim"], depth=self.cfg_kw["depth"]) / 1e9
+        if self.L:       # student fwd + bwd (3x fwd) of every local view; the Gram term does not see them
+            gf += 3.0 * self.L * fwd_flops_per_image(img=self.local_size, dim=self.cfg_kw["dim"], depth=self.cfg_kw["depth"], gram=False) / 1e9
+        return gf
+
+    def step_split(self, n=4) -> dict:
+        """HIP-event milliseconds between the phase boundaries TrainEngine.step marks on its launch stream."""
+        import torch
+        acc: dict = {}
+        for _ in range(n):
+            self.eng.marks = []
+            self.step()
+            torch.cuda.synchronize()
+            m = self.eng.marks
+            for (_, e0), (name, e1) in zip(m[:-1], m[1:]):
+                acc[name] = acc.get(name, 0.0) + e0.elapsed_time(e1)
+        self.eng.marks = None
+        return {k: round(v / n, 3) for k, v in acc.items()}
+
+
+def timed(wl, steps, warmup, barrier, note=None, timer=None):
+    import torch
+    from dinox import ops
+    for i in range(warmup):
+        wl.step()
+        torch.cuda.synchronize()
+        if note:
+            note(f"warm-up step {i} done")
+    if timer is not None:
+        ops.GEMM_TIMER = timer
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        wl.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    ops.GEMM_TIMER = None
+    return dt
+
+
+def secondary(dev, note) -> dict:
+    """Short (3 warm-up + 8 timed steps) measurements of the other single-GPU BASELINE configs, so that the driver's record --
+    not a builder log -- holds them.  Each frees its memory before the next."""
+    import gc
+    import torch
+    out = {}
+    runs = [("bs64_scale_off", dict(B=64, scale_aware=False), "BASELINE configs[1]: ViT-S/16 224, bs 64, scale-aware off, 2 views/sample"),
+            ("bs64_scale_off_graph", dict(B=64, scale_aware=False, graph=True), "configs[1] with the step replayed as one captured hipGraph"),
+            ("multicrop_2g8l", dict(B=256, L=8), "configs[2] read literally: 2 global + 8 local 96px views/sample (extension: the reference has 2 views)"),
+            ("vit_large_bs128", dict(model="vit-large", B=128), "per-GPU shape of configs[4]: ViT-L/16 224, bs 128, scale-aware, Gram on")]
+
+    def sync():
+        torch.cuda.synchronize()
+
+    for name, kw, what in runs:
+        try:
+            wl = Workload(dev, 0, **kw)
+            dt = timed(wl, 8, 3, sync)
+            scal = wl.eng.scalars()
+            sps = wl.B * 8 / dt
+            out[name] = {"workload": what, "value": round(sps, 1), "unit": "samples/s", "ms_per_step": round(1e3 * dt / 8, 3), "steps": 8, "warmup": 3,
+                         "views_per_s": round((2 + wl.L) * sps, 1), "step_tflops": round(sps * wl.gflop_per_sample() / 1e3, 1),
+                         "step_frac_of_mfma_peak": round(sps * wl.gflop_per_sample() / 1e3 / PEAK_BF16_DENSE_TFLOPS, 4), "loss": round(scal["loss"], 4)}
+            note(f"secondary {name}: {out[name]['value']} samples/s, {out[name]['ms_per_step']} ms/step")
+        except Exception as e:                                # a secondary line must never cost the headline line
+            out[name] = {"workload": what, "error": f"{type(e).__name__}: {e}"[:300]}
+            note(f"secondary {name} failed: {out[name]['error']}")
+        wl = None
+        gc.collect()
+        torch.cuda.empty_cache()
+    return out
+
+
+def main() -> None:
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+
+    import torch
+    import torch.distributed as dist
     from dinox import ops
     from dinox.dp import init_process_group
-    from dinox.engine import StepHyperParams, TrainEngine
-    import zoo.arch as arch
-
     from dinox.hostinfo import usable_cpus
+
     torch.set_num_threads(max(1, usable_cpus() // max(1, int(os.environ.get("WORLD_SIZE", "1")))))
     rank, world, local = init_process_group()
     if world != args.gpus:
@@ -108,29 +249,6 @@ def main() -> None:
     local = local % torch.cuda.device_count()        # (rehearsals may put several gloo ranks on one GPU)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-
-    cfg_kw = dict(img_size=224, patch=16, dim=384, depth=12, heads=6, num_registers=4, scale_aware=True)
-    if args.model == "vit-large":
-        cfg_kw.update(dim=1024, depth=24, heads=16)
-    out_dim, B = 8192, args.batch_size
-    torch.manual_seed(0)
-    student = arch.DinoStudentTeacher(arch.PatchViT(**cfg_kw), out_dim)
-    # exercise the scale branch: the reference zero-inits it, training moves it away from zero
-    torch.nn.init.xavier_uniform_(student.backbone.scale_embed.mlp[2].weight)
-    teacher = arch.DinoStudentTeacher(arch.PatchViT(**cfg_kw), out_dim)
-    teacher.load_state_dict(student.state_dict())
-    amp = None if args.fp32 else torch.bfloat16
-    eng = TrainEngine(student.to(dev), teacher.to(dev), out_dim, StepHyperParams(max_steps=args.steps + args.warmup + 10, warmup_steps=5),
-                      amp_dtype=amp)
-
-    g = torch.Generator().manual_seed(1234 + rank)       # per-rank shard of the synthetic global batch
-    batch = torch.randn(2 * B, 3, 224, 224, generator=g).to(dev)
-    sp = (torch.rand(B, 3, generator=g) * torch.tensor([0.52, 0.52, 4.375]) + torch.tensor([0.46, 0.46, 0.625]))
-    sp2 = torch.cat([sp, sp], 0).to(dev)
-    L = args.local_crops
-    loc = torch.randn(L * B, 3, args.local_size, args.local_size, generator=g).to(dev) if L else None
-    spl = torch.cat([sp] * L, 0).to(dev) if L else None
-
     T_START = time.perf_counter()
 
     def note(msg):
@@ -143,37 +261,27 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    B, L = args.batch_size, args.local_crops
+    wl = Workload(dev, rank, model=args.model, B=B, scale_aware=not args.no_scale_aware, L=L, local_size=args.local_size, fp32=args.fp32,
+                  steps_hint=args.steps + args.warmup + 8, graph=args.graph)
     note(f"model + data resident (world {world}, B {B}/GPU, {'fp32' if args.fp32 else 'bf16'})")
-    for i in range(args.warmup):
-        eng.step(batch, sp2, loc, spl)
-        torch.cuda.synchronize()
-        note(f"warm-up step {i} done")
-    timer = None
-    if not args.no_kernel_timing:
-        timer = ops.GemmTimer()
-        ops.GEMM_TIMER = timer
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.step(batch, sp2, loc, spl)
-    barrier()
-    dt = time.perf_counter() - t0
-    ops.GEMM_TIMER = None
+    timer = None if (args.no_kernel_timing or args.graph) else ops.GemmTimer()
+    dt = timed(wl, args.steps, args.warmup, barrier, note, timer)
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
     note(f"timed region: {args.steps} steps in {dt:.3f}s")
-    scal = eng.scalars()
+    scal = wl.eng.scalars()
     if not (scal["loss"] == scal["loss"]):
         raise SystemExit("non-finite loss in the timed region")
-
     kernels = timer.summary() if timer else {}
+    split = wl.step_split() if not args.graph else None     # (every rank: the step holds collectives)
+    overlapped = getattr(wl.eng.bucketer, "fired_in_backward", None)
+
     if rank == 0:
         samples_s = world * B * args.steps / dt
-        gf_sample = 8.0 * fwd_flops_per_image(dim=cfg_kw["dim"], depth=cfg_kw["depth"]) / 1e9
-        if L:                                  # student fwd + bwd (3x fwd) of every local view; the Gram term does not see them
-            gf_sample += 3.0 * L * fwd_flops_per_image(img=args.local_size, dim=cfg_kw["dim"], depth=cfg_kw["depth"], gram=False) / 1e9
+        gf_sample = wl.gflop_per_sample()
         step_tflops = samples_s * gf_sample / 1e3 / world          # per GPU
         roof = {"bound": "mfma", "achieved": None, "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None}
         if kernels:
@@ -203,31 +311,46 @@ def main() -> None:
         # separate run, WRITE_SIZE of this same command; FETCH doubled per the gfx950 correction) -- bench.py cannot
         # run the profiler on itself, so the figure is read from profiles/ and is null when that file is absent.
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
             fam = "dinox::" + roof.get("kernel", "")
-            if fam in pmc and args.model == "vit-small" and B == 256 and not L:
+            if fam in pmc and args.model == "vit-small" and B == 256 and not L and not args.no_scale_aware:
                 roof["traffic"] = pmc[fam]["hbm_bytes_per_launch"]
-                roof["traffic_note"] = "measured avg HBM bytes/launch (PMC, profiles/r01_pmc_traffic.json) beside hbm.algorithmic_bytes_per_launch"
+                roof["traffic_note"] = f"measured avg HBM bytes/launch (PMC, profiles/{PMC_FILE}) beside hbm.algorithmic_bytes_per_launch"
         except (OSError, ValueError, KeyError):
             pass
         roof["step"] = {"gflop_per_sample": round(gf_sample, 2), "achieved": round(step_tflops, 2),
                         "frac": round(step_tflops / PEAK_BF16_DENSE_TFLOPS, 4)}
+        views = "2 views/sample" if not L else f"2 global + {L} local {args.local_size}px views/sample"
+        if args.model == "vit-small":
+            metric = (f"training images/sec (source samples; 2 global + {L} local {args.local_size}px views each; multi-crop extension, the reference has 2 global views) ViT-S/16 224px bs{B}/GPU"
+                      if L else f"training images/sec (source samples; 2 global views each) ViT-S/16 224px bs{B}/GPU")
+        else:
+            metric = "training images/sec (source samples; 2 global views each) ViT-L/16 224px (configs[4] shape, not the headline metric)"
         line = {
-            "metric": (f"training images/sec (source samples; 2 global + {L} local {args.local_size}px views each; multi-crop extension, the reference has 2 global views) ViT-S/16 224px bs{B}/GPU" if L else
-                       "training images/sec (source samples; 2 global views each) ViT-S/16 224px bs256/GPU") if args.model == "vit-small"
-            else "training images/sec (source samples; 2 global views each) ViT-L/16 224px (configs[4] shape, not the headline metric)",
-            "value": round(samples_s, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": metric, "value": round(samples_s, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.fp32 else "bf16", "data": "synthetic",
-            "config": {"workload": ("ViT-S" if args.model == "vit-small" else "ViT-L") + f"/16 224x224x3 2.5D slice stacks, scale-aware, {'2 views/sample' if not L else f'2 global + {L} local {args.local_size}px views/sample'}, DINO+Gram loss, AdamW+EMA",
-                       "per_gpu_batch": B, "global_batch": B * world, "views_per_step": (2 + L) * B * world, "local_crops": L, "tokens": 201, "out_dim": out_dim,
-                       "parallelism": f"dp{world}", "views_per_s": round((2 + L) * samples_s, 2),
+            "config": {"workload": ("ViT-S" if args.model == "vit-small" else "ViT-L") + f"/16 224x224x3 2.5D slice stacks, "
+                                   f"{'scale-aware' if not args.no_scale_aware else 'scale-aware off'}, {views}, DINO+Gram loss, AdamW+EMA",
+                       "per_gpu_batch": B, "global_batch": B * world, "views_per_step": (2 + L) * B * world, "local_crops": L, "tokens": 201, "out_dim": wl.out_dim,
+                       "parallelism": f"dp{world}", "views_per_s": round((2 + L) * samples_s, 2), "hipgraph": bool(args.graph),
                        "loss": round(scal["loss"], 5), "grad_norm": round(scal["grad_norm"], 5)},
             "roofline": roof,
+            "step_ms_split": split,
         }
+        if world > 1 and overlapped is not None:
+            line["config"]["grad_buckets_launched_during_backward"] = f"{overlapped}/{len(wl.eng.bucketer.buckets)}"
+        default_cfg = args.model == "vit-small" and B == 256 and not L and not args.no_scale_aware and not args.fp32
+        if world == 1 and not args.no_secondary and default_cfg:
+            wl = None
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            line["secondary"] = secondary(dev, note)
         if world == 1 and not args.no_cpu_baseline:
             note("timing the CPU oracle (cpu_baseline) ...")
-            line["cpu_baseline"] = cpu_baseline(cfg_kw, out_dim) if args.model == "vit-small" else None
+            line["cpu_baseline"] = cpu_baseline(dict(img_size=224, patch=16, dim=384, depth=12, heads=6, num_registers=4, scale_aware=True), 8192) \
+                if args.model == "vit-small" else None
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

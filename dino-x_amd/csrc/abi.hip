@@ -1,6 +1,8 @@
 // abi.hip -- error plumbing and library-level entry points of libdinox_hip.so.
 #include <cstdarg>
 #include <cstring>
+#include <mutex>
+#include <unordered_map>
 
 #include "common.h"
 
@@ -21,6 +23,25 @@ int fail(int code, const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
   return code;
+}
+
+// Raise a kernel's dynamic-LDS limit, ONCE per (kernel, size).  hipFuncSetAttribute is not a stream operation and must not be
+// issued while a stream is being captured into a hipGraph; after the first eager launch of a shape it is never called again, so
+// a captured step (dinox.engine.TrainEngine(use_graph=True)) holds kernel nodes only.
+int reserve_lds(const void* kern, size_t bytes, const char* what) {
+  if (bytes <= 64 * 1024) return 0;
+  static std::mutex mu;
+  static std::unordered_map<const void*, size_t> granted;
+  std::lock_guard<std::mutex> lk(mu);
+  size_t& have = granted[kern];
+  if (bytes <= have) return 0;
+  const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail((int)e, "%s: cannot reserve %zu B of LDS (%s)", what, bytes, hipGetErrorString(e));
+  }
+  have = bytes;
+  return 0;
 }
 
 int check_launch(const char* what) {

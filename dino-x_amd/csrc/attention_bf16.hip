@@ -696,9 +696,7 @@ static void geometry(int N, int& nblk, int& nwg, int& waves) {
 
 template <typename K>
 static int allow_lds(K kern, size_t bytes) {
-  if (bytes <= 64 * 1024) return 0;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-  return e == hipSuccess ? 0 : (int)e;
+  return reserve_lds(reinterpret_cast<const void*>(kern), bytes, "attention");
 }
 
 int launch_attention_bf16_fwd(const void* qkv, void* o, float* lse, int B, int N, int heads, int d, hipStream_t st) {

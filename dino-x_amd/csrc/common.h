@@ -14,6 +14,7 @@ namespace dinox {
 void set_error(const char* fmt, ...);
 int fail(int code, const char* fmt, ...);
 int check_launch(const char* what);  // hipGetLastError -> 0 or positive hipError_t
+int reserve_lds(const void* kern, size_t bytes, const char* what);  // hipFuncSetAttribute(max dynamic LDS), once per (kernel, size)
 
 #define DX_REQUIRE(cond, code, ...)                  \
   do {                                               \

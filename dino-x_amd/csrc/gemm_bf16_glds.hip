@@ -366,10 +366,7 @@ int launch_gemm_bf16_nt_glds(const GemmParams& p, hipStream_t st) {
 #define GG_L(OUT, ACT, RES, BK, ST, BM)                                                                                  \
   do {                                                                                                                    \
     auto kern = gemm_bf16_nt_glds<OUT, ACT, RES, BK, ST, BM>;                                                             \
-    if (lds > 64 * 1024) {                                                                                                \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      if (e != hipSuccess) return fail((int)e, "gemm_bf16_nt_glds: cannot reserve %zu B of LDS", lds);                    \
-    }                                                                                                                     \
+    if (int rc = reserve_lds(reinterpret_cast<const void*>(kern), lds, "gemm_bf16_nt_glds")) return rc;                  \
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p, tiles_m, tiles_n);                                           \
   } while (0)
 #define GG(OUT, ACT, RES)                                                       \

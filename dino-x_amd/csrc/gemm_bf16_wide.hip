@@ -217,8 +217,7 @@ int launch_gemm_bf16_nt_wide(const GemmParams& p, hipStream_t st) {
 #define GW_L(ACT)                                                                                                         \
   do {                                                                                                                    \
     auto kern = gemm_bf16_nt_wide<ACT>;                                                                                   \
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, GW_LDS); \
-    if (e != hipSuccess) return fail((int)e, "gemm_bf16_nt_wide: cannot reserve %d B of LDS", GW_LDS);                    \
+    if (int rc = reserve_lds(reinterpret_cast<const void*>(kern), GW_LDS, "gemm_bf16_nt_wide")) return rc;                \
     hipLaunchKernelGGL(kern, dim3(ntile), dim3(512), GW_LDS, st, p, (int)ntile, tiles_n);                                 \
   } while (0)
   if (p.epilogue & DINOX_EPI_GELU) GW_L(GW_GELU);

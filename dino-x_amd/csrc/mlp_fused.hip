@@ -280,10 +280,7 @@ static int launch_mlp_fused(const bf16_t* xn, const bf16_t* w1, const float* b1,
   const size_t ring = 3 * (size_t)(32 * D * 2 + D * 64), parkb = 4 * 32 * 512;
   const size_t lds = ring > parkb ? ring : parkb;
   auto kern = mlp_fused_fwd_bf16<ND>;
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return fail((int)e, "mlp_fwd_fused: cannot reserve %zu B of LDS", lds);
-  }
+  if (int rc = reserve_lds(reinterpret_cast<const void*>(kern), lds, "mlp_fwd_fused")) return rc;
   hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(M, (int64_t)MF_BM)), dim3(256), lds, st, xn, w1, b1, w2, b2, res, out, M, H);
   return check_launch("mlp_fwd_fused");
 }

@@ -9,8 +9,14 @@ namespace dinox {
 __global__ __launch_bounds__(256) void adamw_ema_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                         float* __restrict__ v, float* __restrict__ teacher, int64_t n,
                                                         float lr, float wd, float b1, float b2, float eps, float inv_bc1,
-                                                        float inv_sqrt_bc2, float ema, float gscale, float* __restrict__ ws) {
+                                                        float inv_sqrt_bc2, float ema, float gscale, float* __restrict__ ws,
+                                                        const float* __restrict__ hyper) {
   __shared__ float red[16];
+  if (hyper) {                 // per-step scalars from device memory: the launch can be replayed from a captured hipGraph
+    lr = hyper[0];
+    inv_bc1 = hyper[1];
+    inv_sqrt_bc2 = hyper[2];
+  }
   float sq = 0.f;
   const int64_t n4 = n >> 2;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -140,22 +146,37 @@ static unsigned stream_grid(int64_t n, int per_thread) {
 
 using namespace dinox;
 
-extern "C" int dinox_adamw_ema(float* p, const float* g, float* m, float* v, float* teacher, int64_t n, float lr,
-                               float weight_decay, float beta1, float beta2, float eps, int step_t, float ema,
-                               float grad_scale, float* gnorm_sq, float* ws, void* stream) {
+static int adamw_launch(float* p, const float* g, float* m, float* v, float* teacher, int64_t n, float lr, float weight_decay,
+                        float beta1, float beta2, float eps, float inv_bc1, float inv_sqrt_bc2, float ema, float grad_scale,
+                        float* gnorm_sq, float* ws, const float* hyper, void* stream) {
   DX_REQUIRE(p && g && m && v && gnorm_sq && ws, DINOX_EINVAL, "adamw_ema: null pointer");
-  DX_REQUIRE(n > 0 && step_t >= 1, DINOX_EINVAL, "adamw_ema: n=%lld step_t=%d", (long long)n, step_t);
+  DX_REQUIRE(n > 0, DINOX_EINVAL, "adamw_ema: n=%lld", (long long)n);
   DX_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)teacher) & 15) == 0, DINOX_EALIGN,
              "adamw_ema: arenas must be 16-byte aligned");
-  const double bc1 = 1.0 - pow((double)beta1, step_t), bc2 = 1.0 - pow((double)beta2, step_t);
   const unsigned blocks = stream_grid(n, 4);
   hipStream_t st = as_stream(stream);
   hipLaunchKernelGGL(adamw_ema_kernel, dim3(blocks), dim3(256), 0, st, p, g, m, v, teacher, n, lr, weight_decay, beta1, beta2,
-                     eps, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), ema, grad_scale, ws);
+                     eps, inv_bc1, inv_sqrt_bc2, ema, grad_scale, ws, hyper);
   int rc = check_launch("adamw_ema");
   if (rc) return rc;
   hipLaunchKernelGGL(sum_parts, dim3(1), dim3(256), 0, st, ws, (int)blocks, gnorm_sq);
   return check_launch("adamw_ema_norm");
+}
+
+extern "C" int dinox_adamw_ema(float* p, const float* g, float* m, float* v, float* teacher, int64_t n, float lr,
+                               float weight_decay, float beta1, float beta2, float eps, int step_t, float ema,
+                               float grad_scale, float* gnorm_sq, float* ws, void* stream) {
+  DX_REQUIRE(step_t >= 1, DINOX_EINVAL, "adamw_ema: step_t=%d", step_t);
+  const double bc1 = 1.0 - pow((double)beta1, step_t), bc2 = 1.0 - pow((double)beta2, step_t);
+  return adamw_launch(p, g, m, v, teacher, n, lr, weight_decay, beta1, beta2, eps, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), ema,
+                      grad_scale, gnorm_sq, ws, nullptr, stream);
+}
+
+extern "C" int dinox_adamw_ema_dev(float* p, const float* g, float* m, float* v, float* teacher, int64_t n, const float* hyper,
+                                   float weight_decay, float beta1, float beta2, float eps, float ema, float grad_scale,
+                                   float* gnorm_sq, float* ws, void* stream) {
+  DX_REQUIRE(hyper, DINOX_EINVAL, "adamw_ema_dev: null hyper");
+  return adamw_launch(p, g, m, v, teacher, n, 0.f, weight_decay, beta1, beta2, eps, 1.f, 1.f, ema, grad_scale, gnorm_sq, ws, hyper, stream);
 }
 
 extern "C" int dinox_sumsq(const float* x, int64_t n, float* out, float* ws, void* stream) {

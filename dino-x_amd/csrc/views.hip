@@ -165,10 +165,7 @@ extern "C" int dinox_slice_views(const void* raw_u16, const int64_t* view_i, con
   const int F = (int)(VW_T * s + 2.0 * sup) + 4, MAXT = (int)(2.0 * sup) + 3;
   const size_t lds = (size_t)dinox_slice_views_lds_bytes(S, max_crop);
   DX_REQUIRE(lds <= 150 * 1024, DINOX_EUNSUPPORTED, "slice_views: a %d-pixel crop down to %d needs %zu B of LDS (limit 150 KiB)", max_crop, S, lds);
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(slice_views_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return fail((int)e, "slice_views: cannot reserve %zu B of LDS", lds);
-  }
+  if (int rc = reserve_lds(reinterpret_cast<const void*>(slice_views_kernel), lds, "slice_views")) return rc;
   const int tiles = (S + VW_T - 1) / VW_T;
   hipLaunchKernelGGL(slice_views_kernel, dim3((unsigned)(tiles * tiles), 3, (unsigned)V), dim3(VW_THREADS), lds, as_stream(stream),
                      (const unsigned short*)raw_u16, view_i, view_f, out, S, tiles, F, MAXT);

@@ -70,6 +70,7 @@ SIGNATURES = {
     "dinox_koleo_nn": (i32, [vp, i64, vp, vp, i32, i32, i32, i32, vp, vp, vp]),
     "dinox_koleo_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, f32, vp, vp]),
     "dinox_adamw_ema": (i32, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, f32, vp, vp, vp]),
+    "dinox_adamw_ema_dev": (i32, [vp, vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, f32, f32, vp, vp, vp]),
     "dinox_sumsq": (i32, [vp, i64, vp, vp, vp]),
     "dinox_cast_bf16": (i32, [vp, vp, i64, vp]),
     "dinox_cast_transpose_bf16": (i32, [vp, vp, i32, i32, vp]),

@@ -80,7 +80,12 @@ class TrainEngine:
 
     def __init__(self, student: torch.nn.Module, teacher: torch.nn.Module, out_dim: int, hp: StepHyperParams,
                  amp_dtype: Optional[torch.dtype] = None, process_group=None, bucket_bytes: int = 32 << 20,
-                 accumulation_steps: int = 1) -> None:
+                 accumulation_steps: int = 1, use_graph: bool = False) -> None:
+        """``use_graph``: after two eager steps the whole optimiser step (forward, backward, optimiser tail) is captured ONCE into
+        a hipGraph and every later step is one graph launch -- for the launch-bound small-batch regime (at bs 64 the host needs
+        10-14 ms to enqueue the ~700 launches of a step that the GPU finishes in 11).  The C ABI was designed for it: no
+        allocation, no synchronisation, no host-dependent scalar inside a launch (lr and the Adam bias corrections come from
+        device memory, dinox_adamw_ema_dev).  Single rank, accumulation_steps == 1, fixed batch shape."""
         self.student, self.teacher, self.hp = student, teacher, hp
         if accumulation_steps < 1:
             raise ValueError("accumulation_steps must be >= 1")
@@ -109,13 +114,62 @@ class TrainEngine:
         # kernel chains fill each other's tails (every launch ends with a partial last round of workgroups)
         self.side_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self.shadows = [ops.ArenaShadow(self.flat_p, self.params, self.offsets), ops.ArenaShadow(self.flat_t, t_params, t_off)]
+        self.use_graph = bool(use_graph)
+        if self.use_graph and (self.accum != 1 or exchanging(process_group)):
+            raise ValueError("use_graph: single rank and accumulation_steps == 1 only")
+        self._graph = None
+        self._static: Optional[list] = None
+        self._eager_steps = 0
+        self._hyper_dev = torch.zeros(3, dtype=torch.float32, device=dev)
+        self._hyper_host = torch.zeros(3, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(3)
+        self.marks = None            # bench.py: a list -> (phase name, HIP event on the launch stream) at every phase boundary of step()
         self.step_count = 0          # micro-batches seen (drives the LR schedule, like the reference)
         self.opt_steps = 0           # optimiser steps taken (AdamW bias correction)
         self.last = {}
 
+    def _mark(self, name: str) -> None:
+        if self.marks is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.marks.append((name, ev))
+
     # -- one optimiser step ---------------------------------------------------------------------
     def step(self, batch: torch.Tensor, spacing2b: Optional[torch.Tensor] = None, local_batch: Optional[torch.Tensor] = None,
              local_spacing: Optional[torch.Tensor] = None) -> dict:
+        if not self.use_graph:
+            return self._step_eager(batch, spacing2b, local_batch, local_spacing)
+        return self._step_graph([batch, spacing2b, local_batch, local_spacing])
+
+    def _step_graph(self, inputs: list) -> dict:
+        hp = self.hp
+        if self._graph is None and self._eager_steps < 2:       # eager first: LDS limits granted, operand images and tables built
+            self._eager_steps += 1
+            return self._step_eager(*inputs)
+        lr = get_lr(self.step_count, hp.max_steps, hp.warmup_steps, hp.lr, hp.min_lr)
+        self._hyper_host.copy_(torch.tensor(ops.adamw_hyper(lr, hp.beta1, hp.beta2, self.opt_steps + 1), dtype=torch.float32))
+        self._hyper_dev.copy_(self._hyper_host, non_blocking=True)
+        if self._graph is None:
+            self._static = [None if t is None else t.clone() for t in inputs]
+            torch.cuda.synchronize()
+            self._graph = torch.cuda.CUDAGraph()
+            count, opt = self.step_count, self.opt_steps
+            with torch.cuda.graph(self._graph):
+                self._captured = self._step_eager(*self._static, hyper=self._hyper_dev)
+            self.step_count, self.opt_steps = count, opt          # capturing enqueued nothing: the replay below IS this step
+        else:
+            for dst, src in zip(self._static, inputs):
+                if (dst is None) != (src is None) or (dst is not None and dst.shape != src.shape):
+                    raise ValueError("use_graph: the batch layout must not change after capture")
+                if dst is not None:
+                    dst.copy_(src, non_blocking=True)
+        self._graph.replay()
+        self.step_count += 1
+        self.opt_steps += 1
+        self.last = dict(self._captured, lr=lr)
+        return self.last
+
+    def _step_eager(self, batch: torch.Tensor, spacing2b: Optional[torch.Tensor] = None, local_batch: Optional[torch.Tensor] = None,
+                    local_spacing: Optional[torch.Tensor] = None, hyper: Optional[torch.Tensor] = None) -> dict:
         """batch: (2B,3,H,W) = [view1; view2] on the device; spacing2b: (2B,3) or None.
         local_batch (L*B,3,s,s), view-major, with local_spacing (L*B,3): the multi-crop extension (not in the reference) --
         the student also sees L smaller crops per sample, which enter the DINO term only (every (teacher view, other student
@@ -128,6 +182,7 @@ class TrainEngine:
         # of that micro-batch, the centre moves every micro-batch.  Gradients are exchanged once, on the last micro-batch.
         first = self.step_count % self.accum == 0
         last = (self.step_count + 1) % self.accum == 0
+        self._mark("start")
         if first:
             self.flat_g.zero_()
         self.bucketer.active = last
@@ -153,9 +208,11 @@ class TrainEngine:
                 t_out.record_stream(main)
             else:
                 s_feats = self.student.backbone(batch, spacing=spacing2b)
+                self._mark("fwd_student")
                 with torch.no_grad():
                     t_feats = self.teacher.backbone(batch, spacing=spacing2b)
                     t_out = self.teacher.head(t_feats[:, 0])
+                self._mark("fwd_teacher")
             if local_batch is None:
                 s_out = self.student.head(s_feats[:, 0])
                 l_dino = ops.DinoCEFn.apply(s_out, t_out, self.center, hp.student_temp, hp.teacher_temp)
@@ -179,23 +236,27 @@ class TrainEngine:
                 loss = loss + hp.koleo_weight * l_koleo
             else:
                 l_koleo = torch.zeros((), device=batch.device)
+            self._mark("loss")            # (local-crop forward, student head, DINO CE, Gram, KoLeo forward)
             (loss if self.accum == 1 else loss / self.accum).backward()
+        self._mark("bwd")
         if bm_work is not None:
             bm_work.wait()
             bm.div_(self.world)
         ops.center_ema_(self.center.view(-1), bm, hp.center_momentum)
         self.bucketer.finish()
+        self._mark("comm_exposed")        # what of the exchanges did not fit under backward (+ the centre EMA launch)
         if last:
             self.opt_steps += 1
             gsq = ops.adamw_ema_(self.flat_p, self.flat_g, self.adam_m, self.adam_v, self.flat_t, lr=lr,
                                  weight_decay=hp.weight_decay, beta1=hp.beta1, beta2=hp.beta2, eps=hp.adam_eps,
-                                 step_t=self.opt_steps, ema=hp.ema, grad_scale=1.0 / self.world)
+                                 step_t=self.opt_steps, ema=hp.ema, grad_scale=1.0 / self.world, hyper=hyper)
             ops.weight_cache.clear()     # master weights changed under the bf16 copies
             if self.compute_dtype == torch.bfloat16:
                 for sh in self.shadows:  # one cast launch per arena (+ one for every transposed matrix backward uses)
                     sh.refresh()
         else:
             gsq = torch.zeros(1, device=batch.device)       # the reference logs grad-norm 0 between optimiser steps
+        self._mark("optimiser_tail")
         self.step_count += 1
         self.last = {"loss": loss.detach(), "dino": l_dino.detach(), "gram": l_gram.detach(), "koleo": l_koleo.detach(),
                      "grad_norm_sq": gsq, "lr": lr}

@@ -205,9 +205,12 @@ def colsum(x: Tensor, out: Optional[Tensor] = None, accumulate=False) -> Tensor:
     return out
 
 
-def cast_bf16(x: Tensor) -> Tensor:
+def cast_bf16(x: Tensor, out: Optional[Tensor] = None) -> Tensor:
     x = _c(x)
-    out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    else:
+        assert out.dtype == torch.bfloat16 and out.is_contiguous() and out.numel() == x.numel()
     check(lib.dinox_cast_bf16(_p(x), _p(out), x.numel(), _stream()), "dinox_cast_bf16")
     return out
 
@@ -249,7 +252,9 @@ class ArenaShadow:
         self.served_t: set = set()
 
     def refresh(self) -> None:
-        self.plain = cast_bf16(self.flat)
+        # (ONE persistent image, rewritten in place: the operand views handed out earlier stay valid, and a step captured into a
+        # hipGraph reads at replay n + 1 what replay n wrote)
+        self.plain = cast_bf16(self.flat, out=self.plain)
         self.versions = [p._version for p in self.params]
         self.served_t = set()
         if self.wanted:
@@ -1110,14 +1115,26 @@ def koleo_loss(x: Tensor, eps: float = 1e-8, group=None) -> Tensor:
     return KoLeoFn.apply(x, eps, group)
 
 
+def adamw_hyper(lr: float, beta1: float, beta2: float, step_t: int) -> list:
+    """The three per-step scalars of the optimiser pass -- [lr, 1/(1-beta1^t), 1/sqrt(1-beta2^t)] -- for dinox_adamw_ema_dev."""
+    return [lr, 1.0 / (1.0 - beta1 ** step_t), 1.0 / math.sqrt(1.0 - beta2 ** step_t)]
+
+
 def adamw_ema_(p: Tensor, g: Tensor, m: Tensor, v: Tensor, teacher: Optional[Tensor], *, lr: float, weight_decay: float,
-               beta1: float, beta2: float, eps: float, step_t: int, ema: float, grad_scale: float = 1.0) -> Tensor:
-    """Fused grad-norm + AdamW + EMA over flat fp32 arenas; returns gnorm_sq[1] (device)."""
+               beta1: float, beta2: float, eps: float, step_t: int, ema: float, grad_scale: float = 1.0,
+               hyper: Optional[Tensor] = None) -> Tensor:
+    """Fused grad-norm + AdamW + EMA over flat fp32 arenas; returns gnorm_sq[1] (device).  With ``hyper`` (device float[3], see
+    adamw_hyper) lr and the bias corrections are read from device memory: the launch is replayable from a captured hipGraph."""
     _need_cuda(p, g, m, v)
     for t in (p, g, m, v) + ((teacher,) if teacher is not None else ()):
         assert t.is_contiguous() and t.dtype == torch.float32 and t.numel() == p.numel()
     out = torch.empty(1, dtype=torch.float32, device=p.device)
     ws = torch.empty(4096, dtype=torch.float32, device=p.device)
+    if hyper is not None:
+        assert hyper.is_cuda and hyper.dtype == torch.float32 and hyper.numel() == 3
+        check(lib.dinox_adamw_ema_dev(_p(p), _p(g), _p(m), _p(v), _p(teacher), p.numel(), _p(hyper), weight_decay, beta1, beta2, eps, ema,
+                                      grad_scale, _p(out), _p(ws), _stream()), "dinox_adamw_ema_dev")
+        return out
     check(lib.dinox_adamw_ema(_p(p), _p(g), _p(m), _p(v), _p(teacher), p.numel(), lr, weight_decay, beta1, beta2, eps, step_t, ema,
                               grad_scale, _p(out), _p(ws), _stream()), "dinox_adamw_ema")
     return out

@@ -259,6 +259,12 @@ int dinox_koleo_bwd(const float* xh_all, const int* idx_all, const float* dist_a
 int dinox_adamw_ema(float* p, const float* g, float* m, float* v, float* teacher, int64_t n, float lr,
                     float weight_decay, float beta1, float beta2, float eps, int step_t, float ema,
                     float grad_scale, float* gnorm_sq, float* ws, void* stream);
+/* The same pass with its per-step scalars in DEVICE memory -- hyper[3] = {lr, 1/(1-beta1^t), 1/sqrt(1-beta2^t)} -- so that the
+ * launch can sit in a captured hipGraph and be replayed with a new learning rate / step count (the host writes hyper before
+ * each replay).  New in this engine (the reference has no graph capture); same arithmetic as dinox_adamw_ema. */
+int dinox_adamw_ema_dev(float* p, const float* g, float* m, float* v, float* teacher, int64_t n, const float* hyper,
+                        float weight_decay, float beta1, float beta2, float eps, float ema, float grad_scale,
+                        float* gnorm_sq, float* ws, void* stream);
 int dinox_sumsq(const float* x, int64_t n, float* out, float* ws, void* stream);
 int dinox_cast_bf16(const float* src, void* dst, int64_t n, void* stream);
 int dinox_cast_transpose_bf16(const float* src, void* dst, int R, int C, void* stream);

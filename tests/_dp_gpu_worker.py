@@ -16,7 +16,9 @@ import zoo.arch as arch  # noqa: E402
 rank, world, local = init_process_group()
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
-kw = dict(img_size=56, patch=14, dim=64, depth=2, heads=2, num_registers=4, scale_aware=True)
+accum = int(os.environ.get("DINOX_TEST_ACCUM") or 1)
+ckpt = bool(os.environ.get("DINOX_TEST_GRAD_CKPT"))
+kw = dict(img_size=56, patch=14, dim=64, depth=2, heads=2, num_registers=4, scale_aware=True, use_grad_checkpoint=ckpt)
 torch.manual_seed(100 + rank)                      # different init per rank: the engine must broadcast rank 0's weights
 if world == 1:
     torch.manual_seed(100)
@@ -25,7 +27,8 @@ torch.nn.init.xavier_uniform_(student.backbone.scale_embed.mlp[2].weight)
 teacher = arch.DinoStudentTeacher(arch.PatchViT(**kw), 256)
 teacher.load_state_dict(student.state_dict())
 eng = TrainEngine(student.to(dev), teacher.to(dev), 256, StepHyperParams(lr=1e-3, warmup_steps=1, max_steps=10, ema=0.99, koleo_weight=0.1),
-                  bucket_bytes=64 << 10)
+                  bucket_bytes=64 << 10, accumulation_steps=accum)
+student.train()
 assert world == 1 or len(eng.bucketer.buckets) >= 3
 if os.environ.get("DINOX_DP_FORCE_COLLECTIVES"):
     assert eng.bucketer.exchange and torch.distributed.get_backend() == os.environ.get("DINOX_EXPECT_BACKEND", torch.distributed.get_backend())
@@ -36,10 +39,11 @@ sp = torch.rand(B, 3, generator=g) * 2 + 0.4
 lo, hi = shard_range(B, rank, world)
 batch = torch.cat([v1[lo:hi], v2[lo:hi]], 0).to(dev)
 sp2 = torch.cat([sp[lo:hi], sp[lo:hi]], 0).to(dev)
-for _ in range(2):
+for _ in range(2 * accum):                          # two optimiser steps
     eng.step(batch, sp2)
 sc = eng.scalars()
-torch.save({"flat_p": eng.flat_p.cpu(), "center": eng.center.cpu(), "loss": sc["loss"], "grad_norm": sc["grad_norm"]}, sys.argv[1])
+torch.save({"flat_p": eng.flat_p.cpu(), "center": eng.center.cpu(), "loss": sc["loss"], "grad_norm": sc["grad_norm"],
+            "buckets": len(eng.bucketer.buckets), "fired_in_backward": eng.bucketer.fired_in_backward}, sys.argv[1])
 if torch.distributed.is_initialized():
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()

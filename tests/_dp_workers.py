@@ -55,6 +55,38 @@ def bucketer(rank, world, port, out):
     dist.destroy_process_group()
 
 
+def bucketer_accum(rank, world, port, out):
+    """Gradient accumulation x data parallel as TrainEngine.step drives it: the arena is zeroed on the first micro-batch, every
+    micro-batch back-propagates loss / accum into it, the bucketer is armed each time but ACTIVE only on the last one."""
+    init(rank, world, port)
+    from dinox.dp import GradBucketer, shard_range
+    from dinox.engine import flatten_parameters
+    model = toy()
+    flat_p, params, offs = flatten_parameters(model)
+    flat_g = torch.zeros_like(flat_p)
+    for p, o in zip(params, offs):
+        p.grad = flat_g[o:o + p.numel()].view(p.shape)
+    bk = GradBucketer(params, offs, flat_g, bucket_bytes=160)
+    X, Y = toy_data()
+    lo, hi = shard_range(8, rank, world)
+    mid = (lo + hi) // 2
+    accum, fired = 2, []
+    for opt_step in range(2):
+        for k, (a, b) in enumerate(((lo, mid), (mid, hi))):
+            if k == 0:
+                flat_g.zero_()
+            bk.active = k == accum - 1
+            bk.arm()
+            (((model(X[a:b]) - Y[a:b]) ** 2).mean() / accum).backward()
+            fired.append(bk.fired_in_backward)
+            bk.finish()
+    assert fired == [0, len(bk.buckets)] * 2, fired           # nothing is exchanged on the first micro-batch, everything from backward on the last
+    if rank == 0:
+        np.savez(out, flat=(flat_g / world).numpy(), nbuckets=len(bk.buckets))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def oracle_setup():
     from oracle import dinox_oracle as O
     cfg = O.VitCfg(img_size=28, patch=14, dim=32, depth=1, heads=2, num_registers=2, scale_aware=True, out_dim=48)
@@ -92,4 +124,4 @@ def dp_oracle(rank, world, port, out):
 
 if __name__ == "__main__":
     which, rank, world, port, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
-    {"bucketer": bucketer, "dp_oracle": dp_oracle}[which](rank, world, port, out)
+    {"bucketer": bucketer, "bucketer_accum": bucketer_accum, "dp_oracle": dp_oracle}[which](rank, world, port, out)

@@ -23,6 +23,12 @@ Fixtures
   step_tiny.npz       3 consecutive training steps of the reference loop order
                       (phase5_big_run.py:1741-1802) on a 28/14/32/2/2 model
   init_seed0.npz      raw initial state_dict under torch.manual_seed(0) (28/14/32/2/2 model)
+  vit_tiny_autocast.npz  the vit_tiny case again with forward + losses under torch.autocast("cpu", bfloat16) -- the reference's
+                      --amp arithmetic (phase5_big_run.py:1716-1717) -- feats, losses and every parameter gradient; two policies
+                      for the DINO term (fp32 softmax like GPU autocast / CPU autocast as is).  Inputs + weights: vit_tiny.npz
+  ref_checkpoint_00000003.pth  written by the REFERENCE's save_checkpoint (:1104-1125) after 3 steps of its loop order
+  ckpt_tiny.npz       the batches of those steps, the state the checkpoint must restore, and step 4 as the reference runs it after
+                      its own load_checkpoint (:1128-1193) into fresh modules + a fresh torch.optim.AdamW
   get_lr.npz          get_lr at a grid of (step,total)
 """
 from __future__ import annotations
@@ -167,7 +173,7 @@ def koleo_loss():
     save("koleo_loss.npz", **out)
 
 
-def vit_tiny():
+def _vit_tiny_setup():
     g = torch.Generator().manual_seed(31)
     torch.manual_seed(0)
     cfg = dict(img_size=56, patch=14, dim=64, depth=2, heads=2, mlp_ratio=4.0, num_registers=4, scale_aware=True)
@@ -183,6 +189,11 @@ def vit_tiny():
     sp = torch.tensor([[0.5, 0.5, 1.0], [1.5, 1.5, 5.0]])
     sp2 = torch.cat([sp, sp], 0)
     center = 0.05 * torch.randn(1, 128, generator=g)
+    return student, teacher, x, sp2, center
+
+
+def vit_tiny():
+    student, teacher, x, sp2, center = _vit_tiny_setup()
 
     taps = {}
     hooks = [blk.register_forward_hook(lambda m, i, o, k=f"block{j}": taps.__setitem__(k, o.detach().clone()))
@@ -212,6 +223,124 @@ def vit_tiny():
     out.update({f"grad/{n}": p.grad for n, p in student.named_parameters()})
     out["param_order"] = np.array([n for n, _ in student.named_parameters()])
     save("vit_tiny.npz", **out)
+
+
+def vit_tiny_autocast():
+    """The vit_tiny case with the forward and the losses under torch.autocast(bfloat16), as the reference's --amp path runs them
+    (phase5_big_run.py:1716-1717, backward outside the context :1772).  The reference enables autocast on its GPU only; the
+    context is device-generic and this container has no GPU, so it is entered for "cpu".  CPU and GPU autocast share the policy
+    for every op of the model (bf16 linear / conv / SDPA / bmm with bf16 results, GELU in the dtype it is handed, LayerNorm of
+    the fp32 residual stream in fp32, mse_loss fp32) and differ in the DINO term: GPU autocast runs softmax / log_softmax in fp32,
+    CPU autocast leaves them in the head's bf16.  Both are recorded: "f32loss/" hands the loss fp32 copies of the head outputs
+    (= the GPU policy, the tighter reference for the bf16 gates), "cpu/" is CPU autocast as is."""
+    out = {}
+    for tag, loss_fp32 in (("f32loss", True), ("cpu", False)):
+        student, teacher, x, sp2, center = _vit_tiny_setup()
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            s_feats = student.backbone(x, spacing=sp2)
+            with torch.no_grad():
+                t_feats = teacher.backbone(x, spacing=sp2)
+            s_out = student.head(s_feats[:, 0])
+            t_out = teacher.head(t_feats[:, 0])
+            L = P.DINOLoss(128, center_momentum=0.9)
+            L.center.copy_(center)
+            l_dino = L(s_out.float(), t_out.float(), 0.1, 0.04) if loss_fp32 else L(s_out, t_out, 0.1, 0.04)
+            l_gram = P.compute_gram_anchoring_loss(s_feats, t_feats)
+            loss = l_dino + 1.0 * l_gram
+        loss.backward()
+        out.update({f"{tag}/s_feats": s_feats.float(), f"{tag}/t_feats": t_feats.float(), f"{tag}/s_out": s_out.float(),
+                    f"{tag}/t_out": t_out.float(), f"{tag}/loss_dino": l_dino.float(), f"{tag}/loss_gram": l_gram.float(),
+                    f"{tag}/loss": loss.float()})
+        out.update({f"{tag}/grad/{n}": p.grad.float() for n, p in student.named_parameters()})
+        out[f"{tag}/dtypes"] = np.array([str(s_feats.dtype), str(s_out.dtype), str(l_dino.dtype), str(l_gram.dtype)])
+    save("vit_tiny_autocast.npz", **out)
+
+
+def ckpt_tiny():
+    """Cross-implementation checkpoint parity.  Three steps in the reference's loop order, then the REFERENCE's
+    save_checkpoint writes ref_checkpoint_00000003.pth; the reference's load_checkpoint restores it into fresh modules and a
+    fresh AdamW, and step 4 runs from there.  The engine must restore the same file through the CLI's load_checkpoint and
+    reproduce step 4.  Model: what the reference's main() builds for --vit-patch 14 --vit-dim 32 --vit-depth 2 --vit-heads 2
+    --out-dim 64 --img-size 28 --scale-aware (:1594-1608: registers default 4)."""
+    import tempfile
+    from pathlib import Path
+    g = torch.Generator().manual_seed(51)
+    torch.manual_seed(0)
+    mc = P.ModelConfig(name="custom", patch=14, dim=32, depth=2, heads=2, mlp_ratio=4.0, out_dim=64)
+    hp = dict(lr=1e-3, min_lr=1e-5, warmup=2, max_steps=10, wd=0.04, ema=0.9, ts=0.1, tt=0.04, cm=0.9, gw=1.0)
+    tc = P.TrainingConfig(model=mc, img_size=28, batch_size=3, lr=hp["lr"], min_lr=hp["min_lr"], warmup_steps=hp["warmup"],
+                          weight_decay=hp["wd"], max_steps=hp["max_steps"], ema=hp["ema"], teacher_temp=hp["tt"], student_temp=hp["ts"],
+                          center_momentum=hp["cm"], gram_weight=hp["gw"], scale_aware=True, created_at="2026-01-01 00:00:00 UTC")
+
+    def build():
+        kw = dict(img_size=28, patch=mc.patch, dim=mc.dim, depth=mc.depth, heads=mc.heads, mlp_ratio=mc.mlp_ratio,
+                  use_grad_checkpoint=False, scale_aware=True)
+        s = P.DinoStudentTeacher(P.PatchViT(**kw), out_dim=mc.out_dim)
+        t = P.DinoStudentTeacher(P.PatchViT(**kw), out_dim=mc.out_dim)
+        return s, t
+
+    def one_step(step, student, teacher, opt, L, batch, sp2):
+        lr = P.get_lr(step, hp["max_steps"], hp["warmup"], hp["lr"], hp["min_lr"])
+        for pg in opt.param_groups:
+            pg["lr"] = lr
+        s_feats = student.backbone(batch, spacing=sp2)
+        with torch.no_grad():
+            t_feats = teacher.backbone(batch, spacing=sp2)
+        s_out = student.head(s_feats[:, 0])
+        t_out = teacher.head(t_feats[:, 0])
+        loss = L(s_out, t_out, hp["ts"], hp["tt"]) + hp["gw"] * P.compute_gram_anchoring_loss(s_feats, t_feats)
+        loss.backward()
+        gn = sum(p.grad.detach().norm(2).item() ** 2 for p in student.parameters() if p.grad is not None) ** 0.5
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        with torch.no_grad():
+            for ps, pt in zip(student.parameters(), teacher.parameters()):
+                pt.data.mul_(hp["ema"]).add_(ps.data, alpha=1.0 - hp["ema"])
+        return loss.item(), gn, lr
+
+    student, teacher = build()
+    perturb_(student, g)
+    teacher.load_state_dict(student.state_dict())
+    for p in teacher.parameters():
+        p.requires_grad_(False)
+    opt = torch.optim.AdamW(student.parameters(), lr=hp["lr"], weight_decay=hp["wd"])
+    scaler = torch.amp.GradScaler("cpu", enabled=False)
+    L = P.DINOLoss(mc.out_dim, center_momentum=hp["cm"])
+    out = dict(hp=np.array([hp[k] for k in ("lr", "min_lr", "warmup", "max_steps", "wd", "ema", "ts", "tt", "cm", "gw")], dtype=np.float64))
+    out.update(sd_arrays("init", student.state_dict()))
+    batches = []
+    for step in range(4):
+        v = torch.randn(2 * 3, 3, 28, 28, generator=g)
+        sp = torch.rand(3, 3, generator=g) * 2 + 0.4
+        batches.append((v, torch.cat([sp, sp], 0)))
+        out[f"batch{step}"], out[f"spacing{step}"] = batches[-1]
+    losses = [one_step(i, student, teacher, opt, L, *batches[i]) for i in range(3)]
+    path = Path(HERE) / "ref_checkpoint_00000003.pth"
+    P.save_checkpoint(path, 3, student, teacher, opt, scaler, L, tc)                      # <- the reference writes the file
+    out.update(sd_arrays("student3", student.state_dict()))
+    out.update(sd_arrays("teacher3", teacher.state_dict()))
+    out["center3"] = L.center.clone()
+    # resume in the reference: fresh modules, fresh optimiser, its own load_checkpoint, then step 4 (index 3)
+    s2, t2 = build()
+    for p in t2.parameters():
+        p.requires_grad_(False)
+    opt2 = torch.optim.AdamW(s2.parameters(), lr=hp["lr"], weight_decay=hp["wd"])
+    L2 = P.DINOLoss(mc.out_dim, center_momentum=hp["cm"])
+    step0, cfg_back = P.load_checkpoint(path, s2, t2, opt2, scaler, L2, torch.device("cpu"), scale_aware=True)
+    assert step0 == 3 and cfg_back.model.dim == 32
+    l4 = one_step(3, s2, t2, opt2, L2, *batches[3])
+    # (the uninterrupted run gives the same step 4: resume is exact in the reference)
+    l4b = one_step(3, student, teacher, opt, L, *batches[3])
+    assert abs(l4[0] - l4b[0]) < 1e-6 * abs(l4b[0]), (l4, l4b)
+    out.update(sd_arrays("student4", s2.state_dict()))
+    out.update(sd_arrays("teacher4", t2.state_dict()))
+    out["center4"] = L2.center.clone()
+    out["losses"] = np.array([l[0] for l in losses] + [l4[0]], dtype=np.float64)
+    out["grad_norms"] = np.array([l[1] for l in losses] + [l4[1]], dtype=np.float64)
+    out["lrs"] = np.array([l[2] for l in losses] + [l4[2]], dtype=np.float64)
+    out["adam_step4"] = np.float64(float(opt2.state_dict()["state"][0]["step"]))
+    np.savez_compressed(os.path.join(HERE, "ckpt_tiny.npz"), **{k: (npy(v) if torch.is_tensor(v) else v) for k, v in out.items()})
+    print(f"ckpt_tiny.npz + {path.name} ({path.stat().st_size / 1024:.1f} KiB): losses={out['losses']}")
 
 
 def vit_plain():
@@ -311,6 +440,11 @@ def get_lr_grid():
 
 
 if __name__ == "__main__":
+    only = set(sys.argv[1:])
+    if only:
+        for name in only:
+            globals()[name]()
+        sys.exit(0)
     ops_attention()
     ops_mlp()
     ops_scale_embed()
@@ -322,3 +456,5 @@ if __name__ == "__main__":
     step_tiny()
     init_seed0()
     get_lr_grid()
+    vit_tiny_autocast()
+    ckpt_tiny()

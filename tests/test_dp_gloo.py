@@ -59,6 +59,22 @@ def test_bucketed_allreduce_matches_global_batch(tmp_path):
     np.testing.assert_allclose(got["flat"], want.numpy(), rtol=1e-5, atol=1e-7)
 
 
+def test_accumulation_times_data_parallel_exchanges_once_and_matches_global_batch(tmp_path):
+    """accumulation_steps = 2 under 2 ranks: four quarter-batches (2 ranks x 2 micro-batches) of equal size, each scaled by
+    1/accum, summed over micro-batches locally and over ranks ONCE (on the last micro-batch), then / world = the gradient of
+    the mean loss over the whole global batch."""
+    got = _run("bucketer_accum", tmp_path)
+    from dinox.engine import flatten_parameters
+    model = W.toy()
+    flat_p, params, offs = flatten_parameters(model)
+    X, Y = W.toy_data()
+    ((model(X) - Y) ** 2).mean().backward()
+    want = torch.zeros_like(flat_p)
+    for p, o in zip(params, offs):
+        want[o:o + p.numel()] = p.grad.reshape(-1)
+    np.testing.assert_allclose(got["flat"], want.numpy(), rtol=1e-5, atol=1e-7)
+
+
 def test_two_rank_step_equals_global_batch_oracle(tmp_path):
     got = _run("dp_oracle", tmp_path)
     O, cfg, sd, v1, v2, sp, hp = W.oracle_setup()

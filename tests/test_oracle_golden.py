@@ -255,3 +255,41 @@ def test_multicrop_extension_anchors():
         ref = F.interpolate(grid, size=(g_out, g_out), mode="bicubic", align_corners=False)[0].permute(1, 2, 0).reshape(g_out * g_out, 8)
         got = O.interpolate_pos(pos, g_out)
         assert torch.equal(got[:, :1], pos[:, :1]) and torch.allclose(got[0, 1:], ref, atol=2e-6), (g_in, g_out)
+
+
+def _rl(a, b):
+    a, b = torch.as_tensor(a).double().reshape(-1), torch.as_tensor(b).double().reshape(-1)
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("policy", ["f32loss", "cpu"])
+def test_oracle_autocast_mode_is_the_reference_autocast_arithmetic(golden, policy):
+    """The oracle's ``autocast_bf16()`` mode (used on the GPU box to price the reference's --amp rounding at model sizes no
+    fixture covers) against the real reference run under torch.autocast(bfloat16) (vit_tiny_autocast.npz): the two must
+    agree far more closely than either agrees with fp32, for the feats, both losses and every parameter gradient."""
+    g, a = golden("vit_tiny.npz"), golden("vit_tiny_autocast.npz")
+    cfg = _cfg(g["cfg"])
+    student = {k: v.clone().requires_grad_(True) for k, v in sub(g, "student").items()}
+    teacher = sub(g, "teacher")
+    x, sp = t(g["x"]), t(g["spacing"])
+    with O.autocast_bf16(loss_fp32=(policy == "f32loss")):
+        s_feats = O.vit_forward(student, x, sp, cfg, pre="backbone.")
+        with torch.no_grad():
+            t_feats = O.vit_forward(teacher, x, sp, cfg, pre="backbone.")
+            t_out = O.head_forward(teacher, t_feats[:, 0])
+        s_out = O.head_forward(student, s_feats[:, 0])
+        l_dino = O.dino_loss(s_out, t_out, t(g["center"]), 0.1, 0.04)
+        l_gram = O.gram_loss(s_feats, t_feats)
+        loss = l_dino + l_gram
+    loss.backward()
+    assert s_out.dtype == torch.bfloat16 and s_feats.dtype == torch.float32        # the dtype flow the fixture recorded
+    p = policy
+    assert _rl(s_feats, a[f"{p}/s_feats"]) < 1e-6 and _rl(s_out.float(), a[f"{p}/s_out"]) < 1e-6
+    assert float(l_dino) == pytest.approx(float(a[f"{p}/loss_dino"]), rel=1e-6)
+    assert float(l_gram) == pytest.approx(float(a[f"{p}/loss_gram"]), rel=1e-6)
+    for n in [str(s) for s in g["param_order"]]:
+        ref_amp, ref_f32 = a[f"{p}/grad/{n}"], g[f"grad/{n}"]
+        assert _rl(student[n].grad, ref_amp) <= 0.02 * _rl(ref_amp, ref_f32) + 1e-7, n
+    # and the size of the thing being priced: the reference's own --amp step sits 2.5-5 % (rel. L2) from its fp32 step per parameter
+    d = [_rl(a[f"{p}/grad/{n}"], g[f"grad/{n}"]) for n in [str(s) for s in g["param_order"]]]
+    assert 0.02 < min(d) and max(d) < 0.06

@@ -63,7 +63,8 @@ def test_engine_written_checkpoint_resumes_in_the_reference():
     assert step == 3 and cfg.model.dim == 32 and cfg.scale_aware
     # the restored state is the reference's own state after the same three steps (engine steps == reference steps, 1e-3)
     for k, v in sub(g, "student3").items():
-        assert torch.allclose(student.state_dict()[k], v, rtol=1e-3, atol=2e-5), k
+        # (key bias: numerically-zero gradient, Adam moves it by +-lr with a round-off sign -> bounded by 3 steps x lr)
+        assert torch.allclose(student.state_dict()[k], v, rtol=1e-3, atol=3.1e-3 if k.endswith("attn.qkv.bias") else 2e-5), k
     assert torch.allclose(L.center, t(g["center3"]), rtol=1e-4, atol=1e-7)
     assert float(opt.state_dict()["state"][0]["step"]) == 3.0
     # step 4 in the reference's loop order (:1692-1802)
@@ -84,4 +85,4 @@ def test_engine_written_checkpoint_resumes_in_the_reference():
     assert cur_lr == pytest.approx(eng["lr4"], rel=1e-12)
     after = torch.load(os.path.join(GOLDEN, "engine_student_after_step4.pth"), map_location="cpu", weights_only=True)
     for k, v in student.state_dict().items():
-        assert torch.allclose(v, after[k], rtol=1e-3, atol=2e-5), k
+        assert torch.allclose(v, after[k], rtol=1e-3, atol=1.1e-3 if k.endswith("attn.qkv.bias") else 2e-5), k

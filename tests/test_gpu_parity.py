@@ -1352,7 +1352,12 @@ def test_engine_written_checkpoint_payload(dx, tmp_path):
     stock.load_state_dict(payload["opt"])                                      # what the reference does at :1171
     assert float(stock.state_dict()["state"][0]["step"]) == 3.0
     for k, v in sub(g, "student3").items():
-        close(payload["student"][k], v, 1e-3, 2e-5, f"payload student {k}")
+        got_k = payload["student"][k]
+        if k.endswith("attn.qkv.bias"):          # the key bias has a numerically-zero gradient (softmax is invariant to it): Adam turns
+            D = v.numel() // 3                   # round-off into +-lr moves whose sign is noise -> bounded by 3 steps x lr
+            close(got_k[D:2 * D], v[D:2 * D], 0, 3.1e-3, f"payload student {k} (key part)")
+            got_k, v = torch.cat([got_k[:D], got_k[2 * D:]]), torch.cat([v[:D], v[2 * D:]])
+        close(got_k, v, 1e-3, 2e-5, f"payload student {k}")
     close(payload["dino_loss"]["center"], g["center3"], 1e-4, 1e-7, "payload centre")
     eng.step(t(g["batch3"]).to(DEV), t(g["spacing3"]).to(DEV))
     got = eng.scalars()

@@ -687,6 +687,204 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_bf16(const bf16_t* __restric
   }   // active
 }
 
+// Two 16-byte LDS reads of per-query statistics.  __restrict__ for the reason given at rd_tr_pair: without alias-scope metadata
+// hipcc makes these reads wait for every LDS-DMA in flight (here: the next pair's K, V images, requested a moment earlier).
+__device__ __forceinline__ void ld_stats(const float* __restrict__ a, const float* __restrict__ b, float4& x, float4& y) {
+  x = *reinterpret_cast<const float4*>(a);
+  y = *reinterpret_cast<const float4*>(b);
+}
+
+// ------------------------------------------------------------------------------------------ backward, one persistent kernel
+// dQ, dK and dV of a (batch, head) pair from ONE residency of its data: the two-kernel form above reads K, V images + q, dO, O rows
+// (dQ kernel) and then Q, dO images + k, v rows (dKV kernel) -- 950 MB per layer at the hot-path shape, 632 MB if every tensor
+// moves once -- and each of its workgroups spends its first third filling LDS with nothing to overlap.  Here one workgroup per CU
+// (one wave per 32 tokens, N <= 224) walks the pairs with FOUR images in LDS:
+//     phase 1 (dQ)   wave w = query block w.  K, V images; own q, dO, O rows in registers (requested one pair ahead);
+//                    delta = rowsum(dO o O) and lse go to LDS for phase 2; then the wave's k, v rows are lifted out of the images.
+//     phase 2 (dKV)  wave w = key block w.  Q, dO images + the statistics in LDS; k, v rows from registers.
+// and every load runs under the OTHER phase's arithmetic: Q, dO of pair p are requested (LDS-DMA) at the top of phase 1 of p, which
+// does not touch those buffers; K, V of pair p + 1 and the rows of p + 1 at the top of phase 2 of p.  Results leave one phase late
+// (dQ at the top of phase 2, dK / dV at the top of the next phase 1) through a per-wave LDS staging tile as 128-byte rows: vmcnt
+// counts stores too, so a store issued right before a phase boundary's wait would be waited for (attention forward log).
+__global__ __launch_bounds__(448) void attn_bwd_fused_bf16(const bf16_t* __restrict__ d_o, const bf16_t* __restrict__ qkv,
+                                                           const bf16_t* __restrict__ o, const float* __restrict__ lse,
+                                                           bf16_t* __restrict__ dqkv, int N, int heads, int nt, float sc, int npairs) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int C = heads * AT_D, hl = lane >> 5;
+  const int64_t rs = 3 * (int64_t)C;
+  const int npad = nt * 32, img_bytes = npad * 128;
+  char* const kimg = smem;
+  char* const vimg = smem + img_bytes;
+  char* const qimg = smem + 2 * img_bytes;
+  char* const doimg = smem + 3 * img_bytes;
+  float* const lse2_s = reinterpret_cast<float*>(smem + 4 * img_bytes);      // lse * log2(e), query-indexed (+inf for padded queries)
+  float* const del_s = lse2_s + npad;
+  char* const st_scratch = smem + 4 * img_bytes + 2 * npad * (int)sizeof(float) + wv * ST_BYTES;
+  int pair = blockIdx.x;
+  if (pair >= npairs) return;
+  const int t0 = wv * 32;                                                    // this wave's token block (queries in phase 1, keys in phase 2)
+  int trow = t0 + (lane & 31);
+  trow = trow < N ? trow : N - 1;
+
+  auto qkv_of = [&](int pr) { return qkv + (int64_t)(pr / heads) * N * rs + (pr % heads) * AT_D; };
+  auto do_of = [&](int pr) { return (int64_t)(pr / heads) * N * C + (pr % heads) * AT_D; };
+  auto issue_kv = [&](int pr) {
+    dma_image(kimg, qkv_of(pr) + C, rs, N, npad, wv, nw, lane);
+    dma_image(vimg, qkv_of(pr) + 2 * C, rs, N, npad, wv, nw, lane);
+  };
+  auto issue_qdo = [&](int pr) {
+    dma_image(qimg, qkv_of(pr), rs, N, npad, wv, nw, lane);
+    dma_image(doimg, d_o + do_of(pr), C, N, npad, wv, nw, lane);
+  };
+  bf16x8 qf[4], dof[4], of[4];
+  float L = 0.f;
+  auto load_rows = [&](int pr) {
+    load_row_frags(qf, qkv_of(pr) + (int64_t)trow * rs, lane);
+    load_row_frags(dof, d_o + do_of(pr) + (int64_t)trow * C, lane);
+    load_row_frags(of, o + do_of(pr) + (int64_t)trow * C, lane);
+    L = lse[(int64_t)pr * N + trow];                                          // (pair index = b * heads + h)
+  };
+  RowAddr ra;
+  TrAddr ta;
+  ra.init(lane);
+  ta.init(lane);
+  const float c2 = sc * 1.4426950408889634f;
+  f32x16 dk[2], dv[2];
+  int prev = -1;
+
+  issue_kv(pair);
+  load_rows(pair);
+  for (; pair < npairs; pair += gridDim.x) {
+    // ---------------- top: K, V images and the rows of this pair have landed; everyone has left phase 2 of the previous pair
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // (hipcc does not see through the asm wait: shown a use of the prefetched rows here, it retires them in ITS bookkeeping now and
+    //  not with a vmcnt(0) in front of their first arithmetic use -- which would also wait for the Q, dO images requested below)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qf[ks]), "+v"(dof[ks]), "+v"(of[ks]));
+    asm volatile("" : "+v"(L));
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    issue_qdo(pair);                                                          // lands under phase 1
+    if (prev >= 0) {                                                          // dK, dV of the previous pair, one phase late
+      bf16_t* dkb = dqkv + (int64_t)(prev / heads) * N * rs + (prev % heads) * AT_D + C;
+      store_block(dkb, rs, t0, N, dk[0], dk[1], st_scratch, lane);
+      store_block(dkb + C, rs, t0, N, dv[0], dv[1], st_scratch, lane);
+    }
+    // ---------------- phase 1: dQ of query block wv
+    float delta = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) delta += (float)dof[ks][j] * (float)of[ks][j];
+    delta += __shfl_xor(delta, 32, 64);
+    const float L2 = L * 1.4426950408889634f;
+    if (hl == 0) {
+      const bool real = t0 + lane < N;
+      lse2_s[t0 + lane] = real ? L2 : INFINITY;                               // exp2(x - inf) = 0: padded queries vanish in phase 2
+      del_s[t0 + lane] = real ? delta : 0.f;
+    }
+    f32x16 dq[2];
+    zero16(dq[0]);
+    zero16(dq[1]);
+#pragma unroll 1
+    for (int kt = 0; kt < nt; ++kt) {
+      f32x16 st, dp;
+      zero16(st);
+      zero16(dp);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_rows(kimg, ra, ks, kt), qf[ks], st, 0, 0, 0);      // S^T[key][q]
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_rows(vimg, ra, ks, kt), dof[ks], dp, 0, 0, 0);     // dP^T[key][q]
+      }
+      if (kt == nt - 1) {                                                     // padded keys only in the last tile
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float p = __builtin_amdgcn_exp2f(st[e] * c2 - L2);
+          st[e] = kt * 32 + acc_row(e, hl) < N ? p * (dp[e] - delta) * sc : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) st[e] = __builtin_amdgcn_exp2f(st[e] * c2 - L2) * (dp[e] - delta) * sc;   // dS^T (scaled)
+      }
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+        const bf16x8 a = acc_as_a(st, ss);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+          dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, rd_tr_pair(kimg + ta.off[ss][dt][0] + kt * 4096, kimg + ta.off[ss][dt][1] + kt * 4096),
+                                                           dq[dt], 0, 0, 0);
+      }
+    }
+    // the wave's k, v rows for phase 2 come out of the images (rows >= N repeat row N - 1, like a clamped row load)
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      kf[ks] = rd_rows(kimg, ra, ks, wv);
+      vf[ks] = rd_rows(vimg, ra, ks, wv);
+    }
+    // ---------------- middle: Q, dO images landed; everyone has left phase 1 (K, V buffers free, statistics complete)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    const int nxt = pair + gridDim.x;
+    if (nxt < npairs) {
+      issue_kv(nxt);                                                          // land under phase 2
+      load_rows(nxt);
+    }
+    {
+      bf16_t* dqb = dqkv + (int64_t)(pair / heads) * N * rs + (pair % heads) * AT_D;
+      store_block(dqb, rs, t0, N, dq[0], dq[1], st_scratch, lane);            // dQ, one phase late
+    }
+    // ---------------- phase 2: dK, dV of key block wv
+    zero16(dk[0]); zero16(dk[1]); zero16(dv[0]); zero16(dv[1]);
+#pragma unroll 1
+    for (int qt = 0; qt < nt; ++qt) {
+      f32x16 st, dp;
+      zero16(st);
+      zero16(dp);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_rows(qimg, ra, ks, qt), kf[ks], st, 0, 0, 0);      // S[q][key]
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_rows(doimg, ra, ks, qt), vf[ks], dp, 0, 0, 0);     // dP[q][key]
+      }
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int q = qt * 32 + 8 * g4 + 4 * hl;
+        float4 l4, d4;
+        ld_stats(lse2_s + q, del_s + q, l4, d4);
+        const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dvv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int e = 4 * g4 + r;
+          const float p = __builtin_amdgcn_exp2f(st[e] * c2 - lv[r]);
+          st[e] = p;                                                          // P
+          dp[e] = p * (dp[e] - dvv[r]) * sc;                                  // dS (scaled)
+        }
+      }
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+        const bf16x8 pa = acc_as_a(st, ss), da = acc_as_a(dp, ss);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, rd_tr_pair(doimg + ta.off[ss][dt][0] + qt * 4096, doimg + ta.off[ss][dt][1] + qt * 4096),
+                                                           dv[dt], 0, 0, 0);
+          dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, rd_tr_pair(qimg + ta.off[ss][dt][0] + qt * 4096, qimg + ta.off[ss][dt][1] + qt * 4096),
+                                                           dk[dt], 0, 0, 0);
+        }
+      }
+    }
+    prev = pair;
+  }
+  {
+    bf16_t* dkb = dqkv + (int64_t)(prev / heads) * N * rs + (prev % heads) * AT_D + C;
+    store_block(dkb, rs, t0, N, dk[0], dk[1], st_scratch, lane);
+    store_block(dkb + C, rs, t0, N, dv[0], dv[1], st_scratch, lane);
+  }
+}
+
 // ------------------------------------------------------------------------------------------ launchers
 static void geometry(int N, int& nblk, int& nwg, int& waves) {
   nblk = (N + 31) / 32;
@@ -741,6 +939,19 @@ int launch_attention_bf16_bwd(const void* d_o, const void* qkv, const void* o, c
   int nblk, nwg, waves;
   geometry(N, nblk, nwg, waves);
   const float sc = 1.0f / sqrtf((float)d);
+  {
+    // one persistent kernel (N <= 224): every tensor moves once, loads run under the other phase's arithmetic
+    const size_t ldsf = (size_t)4 * nblk * 32 * 128 + 2 * (size_t)nblk * 32 * sizeof(float) + (size_t)nblk * ST_BYTES;
+    static const bool split = getenv("DINOX_ATTN_BWD_SPLIT") != nullptr;
+    if (nblk <= 7 && ldsf <= 160 * 1024 && !split) {
+      const int npairs = B * heads;
+      const int nwgp = npairs < 256 ? npairs : 256;
+      if (int rc = allow_lds(attn_bwd_fused_bf16, ldsf)) return fail(rc, "attention_bwd: cannot reserve %zu B of LDS", ldsf);
+      hipLaunchKernelGGL(attn_bwd_fused_bf16, dim3(nwgp), dim3(nblk * 64), ldsf, st, (const bf16_t*)d_o, (const bf16_t*)qkv, (const bf16_t*)o, lse,
+                         (bf16_t*)dqkv, N, heads, nblk, sc, npairs);
+      return check_launch("attention_bf16_bwd_fused");
+    }
+  }
   dim3 grid((unsigned)(B * heads), (unsigned)nwg), block((unsigned)(waves * 64));
   const size_t lds1 = (size_t)2 * nblk * 32 * 128;
   const size_t lds2 = lds1 + (size_t)2 * nblk * 32 * sizeof(float);

@@ -436,8 +436,6 @@ bool gemm_bf16_nt_glds_ok(const GemmParams& p);
 int launch_gemm_bf16_nt_glds(const GemmParams& p, hipStream_t st);
 bool gemm_bf16_nt_areg_ok(const GemmParams& p);
 int launch_gemm_bf16_nt_areg(const GemmParams& p, hipStream_t st);
-bool gemm_bf16_nt_wide_ok(const GemmParams& p);
-int launch_gemm_bf16_nt_wide(const GemmParams& p, hipStream_t st);
 
 const char* gemm_bf16_variant(const GemmParams& p) {
   if (p.in_dtype != DINOX_BF16) return nullptr;
@@ -451,11 +449,6 @@ const char* gemm_bf16_variant(const GemmParams& p) {
     const char* e = getenv("DINOX_NT_AREG_MAXK");
     const int64_t maxk = e ? atoll(e) : 576;
     static const bool no_areg = getenv("DINOX_NT_NO_AREG") != nullptr;
-    // DINOX_NT_WIDE=1: wide outputs (N = 3D, 4D: qkv, fc1, the GELU' product) at short K on 128 x 384 tiles (gemm_bf16_wide.hip).
-    // Opt-in: its K loop is 17-23 % shorter (tools/tile_probe.hip) but the whole kernel measures qkv 153 vs 144 us, fc1 231 vs 218,
-    // teacher fc1 197 vs 202, GELU' product 274 vs 202 (no prefetch of the side tensor yet) against the register-prefetch kernel.
-    const char* we = getenv("DINOX_NT_WIDE");
-    if (we && atoi(we) != 0 && p.K <= 576 && gemm_bf16_nt_wide_ok(p)) return "gemm_bf16_nt_wide";
     return !no_areg && p.K <= maxk && gemm_bf16_nt_areg_ok(p) ? "gemm_bf16_nt_areg" : "gemm_bf16_nt_glds";
   }
   if (p.transA == 0 && p.transB == 0 && (p.K & 7) == 0) return "gemm_bf16_nt";
@@ -469,7 +462,7 @@ const char* gemm_bf16_variant(const GemmParams& p) {
 int launch_gemm_bf16(const GemmParams& p, hipStream_t st) {
   const char* v = gemm_bf16_variant(p);
   if (!v) return DINOX_EUNSUPPORTED;
-  if (v[10] == 'n' && v[12] == '_') return v[13] == 'a' ? launch_gemm_bf16_nt_areg(p, st) : v[13] == 'w' ? launch_gemm_bf16_nt_wide(p, st) : launch_gemm_bf16_nt_glds(p, st);
+  if (v[10] == 'n' && v[12] == '_') return v[13] == 'a' ? launch_gemm_bf16_nt_areg(p, st) : launch_gemm_bf16_nt_glds(p, st);
   const int tiles_m = (int)ceil_div(p.M, GB_BM), tiles_n = (int)ceil_div(p.N, GB_BN);
   const int64_t ntile = (int64_t)tiles_m * tiles_n;
   if (ntile > 0x7fffffff || p.batch > 65535) return DINOX_EUNSUPPORTED;

@@ -1,0 +1,260 @@
+// gemm_bf16_rowln.hip -- x_new = residual + a W^T + bias  AND  y = LayerNorm(x_new)  in ONE kernel, for model width N = 384.
+//
+// Replaces, per transformer block and network pass (reference zoo/arch.py:94-97):
+//     proj / fc2 product (+ bias + residual add)      one NT GEMM writing the fp32 residual stream (158 MB at bs 256) ...
+//     nn.LayerNorm of the next sub-block              ... which a LayerNorm launch read straight back (51 us, 48 launches per step)
+// with one launch on 128 x 384 tiles: a workgroup owns 128 COMPLETE rows of the residual stream, so its epilogue can emit
+// x_new (fp32, the residual stream the backward pass and the next residual add need), LayerNorm(x_new) in the GEMM operand dtype
+// of the consumer (bf16; fp32 for the model's final norm) and the row statistics (mean, rstd) the LayerNorm backward needs.
+//
+// K loop (from the 128 x 384 probe of DESIGN.md section 4 / the former opt-in gemm_bf16_wide.hip, whose tests it passed): eight
+// waves 2 x 4, each 64 rows x 96 columns = 96 accumulator registers; operands global -> LDS by LDS-DMA into [rows][32 k] images (64 B
+// per row, 16-B chunk c of row r at c ^ ((r >> 2) & 3), swizzle applied to the SOURCE address); two-slot ring, per step:
+// vmcnt(0) + lgkmcnt(0) + barrier, request step kt + 1, 12 MFMAs (32x32x16) per wave; two workgroups per CU.
+//
+// The MFMA operands are SWAPPED (weights as the A operand, tokens as B), so an accumulator block is [32 features][32 tokens] and a
+// lane holds, of token row (lane & 31), four runs of 4 consecutive features per block -- 48 of the wave's 96 columns of that row,
+// the other 48 sit in lane ^ 32.  The epilogue therefore needs NO parking in LDS and no passes: x = acc + bias + residual is
+// formed in place in the 96 accumulator registers and stored as 16-byte pieces (a first version parked 16-row slices in LDS and
+// re-read them by rows: four workgroup barriers per tile, ~30 spilled registers, projLN 150 us against 91 + 52 us for the two
+// launches it replaces); a row's sum and M2 over the wave's 96 columns are 48 lane-local terms + one exchange with lane ^ 32
+// (two passes over registers: exact, no E[x^2] - mean^2 cancellation); the four column-waves of a row meet through 8 bytes of LDS
+// per wave and row and ONE workgroup barrier per tile and merge by Chan's formula (equal counts: mean = avg of means, M2 = sum M2
+// + 96 sum (mean_w - mean)^2); y = (x - mean) rstd gamma + beta is packed to bf16 and widened to 16-byte stores by
+// v_permlane32_swap (guide T21: lanes i / i + 32 hold columns 8k..8k+3 / 8k+4..8k+7 of the same row).
+#include "common.h"
+#include "gemm_common.h"
+
+namespace dinox {
+
+typedef __attribute__((address_space(3))) void rl_lds_void;
+typedef __attribute__((address_space(1))) const void rl_gbl_void;
+typedef unsigned rl_u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int RL_BM = 128, RL_BN = 384, RL_BK = 32;
+constexpr int RL_ATILE = RL_BM * 64, RL_BTILE = RL_BN * 64, RL_SLOT = RL_ATILE + RL_BTILE;       // 8 + 24 = 32 KiB
+constexpr int RL_VEC = 2 * RL_SLOT;                 // bias | gamma | beta slices (3 x 384 floats)
+constexpr int RL_STAT = RL_VEC + 3 * RL_BN * 4;     // [128 rows][4 column-waves] x (mean, M2)
+constexpr int RL_LDS = RL_STAT + RL_BM * 4 * 8;     // 64 KiB + 4.5 KiB + 4 KiB
+
+struct RowLnParams {
+  const bf16_t* A;       // [M][K]
+  const bf16_t* W;       // [384][K]
+  const float* bias;     // [384] or null
+  const float* residual; // [M][384] fp32 or null
+  float* x_out;          // [M][384] fp32
+  const float* gamma;    // [384]
+  const float* beta;     // [384]
+  void* y;               // [M][384] bf16 or fp32
+  float* mean;           // [M]
+  float* rstd;           // [M]
+  int64_t M;
+  int K;
+  float eps;
+};
+
+template <int Y_DT>
+__global__ __launch_bounds__(512, 4) void gemm_bf16_rowln(RowLnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wv >> 2, wc = wv & 3;                                   // 2 x 4 waves, each 64 rows x 96 columns
+  const int64_t m0 = (int64_t)blockIdx.x * RL_BM;
+  float* const vec_s = reinterpret_cast<float*>(smem + RL_VEC);
+  if (threadIdx.x < RL_BN) {
+    vec_s[threadIdx.x] = p.bias ? p.bias[threadIdx.x] : 0.f;
+    vec_s[RL_BN + threadIdx.x] = p.gamma[threadIdx.x];
+    vec_s[2 * RL_BN + threadIdx.x] = p.beta[threadIdx.x];
+  }
+
+  // ---- staging: one DMA instruction per wave for A (16 rows x 64 B), three for W; SGPR base + 32-bit per-lane offset
+  const char* abase = (const char*)(p.A + m0 * p.K);
+  const char* bbase = (const char*)p.W;
+  unsigned avoff, bvoff[3];
+  {
+    const int mrem = (int)(p.M - m0 < RL_BM ? p.M - m0 : RL_BM) - 1;    // last valid row of the tile
+    const int row = wv * 16 + (lane >> 2), c = (lane & 3) ^ ((row >> 2) & 3);
+    avoff = (unsigned)(((int64_t)(row < mrem ? row : mrem) * p.K + c * 8) * 2);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int rb = (wv * 3 + q) * 16 + (lane >> 2), cb = (lane & 3) ^ ((rb >> 2) & 3);
+      bvoff[q] = (unsigned)(((int64_t)rb * p.K + cb * 8) * 2);
+    }
+  }
+  auto stage = [&](int slot, int kt) {
+    char* sa = smem + slot * RL_SLOT + wv * 1024;
+    char* sb = smem + slot * RL_SLOT + RL_ATILE + wv * 3072;
+    __builtin_amdgcn_global_load_lds((rl_gbl_void*)(abase + avoff + kt * 64), (rl_lds_void*)sa, 16, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) __builtin_amdgcn_global_load_lds((rl_gbl_void*)(bbase + bvoff[q] + kt * 64), (rl_lds_void*)(sb + q * 1024), 16, 0, 0);
+  };
+
+  f32x16 acc[2][3];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const int nk = p.K / RL_BK, frow = lane & 31, fh = lane >> 5;
+  stage(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int slot = kt & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this step's pieces (and, at kt = 0, the vector loads)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the previous step's fragment reads: its slot is refilled below
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + 1 < nk) stage(slot ^ 1, kt + 1);
+    const char* sa = smem + slot * RL_SLOT;
+    const char* sb = sa + RL_ATILE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[2], bfr[3];
+      const int kc = 2 * ks + fh;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int ra = wr * 64 + i * 32 + frow;
+        af[i] = *reinterpret_cast<const bf16x8*>(sa + ra * 64 + ((kc ^ ((ra >> 2) & 3)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int rb = wc * 96 + j * 32 + frow;
+        bfr[j] = *reinterpret_cast<const bf16x8*>(sb + rb * 64 + ((kc ^ ((rb >> 2) & 3)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);   // [features][tokens]
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+  // ---- epilogue.  acc[i][j][r]: token row wr*64 + i*32 + frow, feature wc*96 + j*32 + 8*(r >> 2) + 4*fh + (r & 3).
+  // Every global access is (wave-uniform 64-bit base in SGPRs) + (32-bit per-lane offset) + (immediate).
+  float2* const stat = reinterpret_cast<float2*>(smem + RL_STAT);
+  const int64_t mw = m0 + wr * 64;
+  const int colq = wc * 96 + 4 * fh;                                                // + j*32 + 8*g: the lane's runs of 4 columns
+  const int nrows = (int)(p.M - mw < 0 ? 0 : (p.M - mw > 64 ? 64 : p.M - mw));     // valid rows of the wave's 64-row block (uniform)
+  const int64_t mwl = nrows > 0 ? mw : p.M - 1;                                    // loads stay inside the tensors
+  const char* const rbase = (const char*)(p.residual ? p.residual + mwl * RL_BN : p.x_out);
+  char* const xbase = (char*)(p.x_out + mw * RL_BN);
+  char* const ybase = (char*)p.y + mw * RL_BN * (Y_DT == DINOX_BF16 ? 2 : 4);
+  const bool has_res = p.residual != nullptr;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = i * 32 + frow;                                          // row inside the wave's block
+    const bool live = r < nrows;
+    const int rl = live ? r : (nrows > 0 ? nrows - 1 : 0);
+    const unsigned loff = (unsigned)((rl * RL_BN + colq) * 4);
+    const unsigned soff = (unsigned)((r * RL_BN + colq) * 4);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      float4 rr[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        rr[g] = has_res ? *reinterpret_cast<const float4*>(rbase + loff + (j * 32 + 8 * g) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 b4 = *reinterpret_cast<const float4*>(vec_s + colq + j * 32 + 8 * g);
+        const float x0 = acc[i][j][4 * g] + b4.x + rr[g].x, x1 = acc[i][j][4 * g + 1] + b4.y + rr[g].y;
+        const float x2 = acc[i][j][4 * g + 2] + b4.z + rr[g].z, x3 = acc[i][j][4 * g + 3] + b4.w + rr[g].w;
+        acc[i][j][4 * g] = x0;
+        acc[i][j][4 * g + 1] = x1;
+        acc[i][j][4 * g + 2] = x2;
+        acc[i][j][4 * g + 3] = x3;
+        s += (x0 + x1) + (x2 + x3);
+        if (live) *reinterpret_cast<float4*>(xbase + soff + (j * 32 + 8 * g) * 4) = make_float4(x0, x1, x2, x3);
+      }
+    }
+    s += __shfl_xor(s, 32, 64);                                           // the other 48 columns of the wave's 96
+    const float mw_ = s * (1.0f / 96.0f);
+    float m2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float d = acc[i][j][e] - mw_;
+        m2 += d * d;
+      }
+    m2 += __shfl_xor(m2, 32, 64);
+    if (fh == 0) stat[(wr * 64 + r) * 4 + wc] = make_float2(mw_, m2);
+  }
+  __syncthreads();                                                        // the four column-waves of every row have written
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = i * 32 + frow;
+    const bool live = r < nrows;
+    const unsigned soff = (unsigned)((r * RL_BN + colq) * 4);
+    const float4 s01 = *reinterpret_cast<const float4*>(stat + (wr * 64 + r) * 4);
+    const float4 s23 = *reinterpret_cast<const float4*>(stat + (wr * 64 + r) * 4 + 2);
+    const float mean = 0.25f * ((s01.x + s01.z) + (s23.x + s23.z));
+    const float d0 = s01.x - mean, d1 = s01.z - mean, d2 = s23.x - mean, d3 = s23.z - mean;
+    const float var = ((s01.y + s01.w) + (s23.y + s23.w) + 96.0f * ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3))) * (1.0f / 384.0f);
+    const float rstd = rsqrtf(var + p.eps);
+    if (live && wc == 0 && fh == 0) {
+      p.mean[mw + r] = mean;
+      p.rstd[mw + r] = rstd;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      unsigned pk[4][2];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 g4 = *reinterpret_cast<const float4*>(vec_s + RL_BN + colq + j * 32 + 8 * g);
+        const float4 b4 = *reinterpret_cast<const float4*>(vec_s + 2 * RL_BN + colq + j * 32 + 8 * g);
+        const float y0 = (acc[i][j][4 * g] - mean) * rstd * g4.x + b4.x, y1 = (acc[i][j][4 * g + 1] - mean) * rstd * g4.y + b4.y;
+        const float y2 = (acc[i][j][4 * g + 2] - mean) * rstd * g4.z + b4.z, y3 = (acc[i][j][4 * g + 3] - mean) * rstd * g4.w + b4.w;
+        if (Y_DT == DINOX_BF16) {
+          pk[g][0] = (unsigned)f32_to_bf16(y0) | ((unsigned)f32_to_bf16(y1) << 16);
+          pk[g][1] = (unsigned)f32_to_bf16(y2) | ((unsigned)f32_to_bf16(y3) << 16);
+        } else if (live) {
+          *reinterpret_cast<float4*>(ybase + soff + (j * 32 + 8 * g) * 4) = make_float4(y0, y1, y2, y3);
+        }
+      }
+      if (Y_DT == DINOX_BF16) {
+        // lanes i / i + 32 hold columns 8g..8g+3 / 8g+4..8g+7: one half-exchange per dword and pair of groups gives the lower
+        // lane columns 8g..8g+7 and the upper lane 8g+8..8g+15 -> one 16-byte store each (guide T21)
+#pragma unroll
+        for (int g = 0; g < 4; g += 2) {
+          const auto e0 = __builtin_amdgcn_permlane32_swap(pk[g][0], pk[g + 1][0], false, false);
+          const auto e1 = __builtin_amdgcn_permlane32_swap(pk[g][1], pk[g + 1][1], false, false);
+          const rl_u32x4 out = {e0[0], e1[0], e0[1], e1[1]};
+          // byte offset of column (wc*96 + j*32 + 8g) in a bf16 row, + 16 for the upper lanes; soff/2 = (r*384 + wc*96 + 4fh)*2
+          if (live) *reinterpret_cast<rl_u32x4*>(ybase + (soff >> 1) - 8 * fh + 16 * fh + (j * 32 + 8 * g) * 2) = out;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace dinox
+
+using namespace dinox;
+
+extern "C" int dinox_linear_residual_ln_ok(int64_t M, int N, int K) {
+  return (N == RL_BN && K >= RL_BK && K % RL_BK == 0 && M >= 1 && M * (int64_t)K * 2 < ((int64_t)1 << 40) &&
+          (int64_t)RL_BM * K * 2 < ((int64_t)1 << 31)) ? 1 : 0;
+}
+
+extern "C" int dinox_linear_residual_ln(const void* a, const void* w, const float* bias, const float* residual, float* x_out,
+                                        const float* gamma, const float* beta, float eps, void* y, int y_dtype, float* mean,
+                                        float* rstd, int64_t M, int N, int K, void* stream) {
+  DX_REQUIRE(a && w && x_out && gamma && beta && y && mean && rstd, DINOX_EINVAL, "linear_residual_ln: null pointer");
+  DX_REQUIRE(dinox_linear_residual_ln_ok(M, N, K), DINOX_EUNSUPPORTED, "linear_residual_ln: M=%lld N=%d K=%d (needs N = 384, K %% 32 = 0)",
+             (long long)M, N, K);
+  DX_REQUIRE(y_dtype == DINOX_BF16 || y_dtype == DINOX_F32, DINOX_EINVAL, "linear_residual_ln: y_dtype=%d", y_dtype);
+  DX_REQUIRE((((uintptr_t)a | (uintptr_t)w | (uintptr_t)residual | (uintptr_t)x_out | (uintptr_t)y) & 15) == 0, DINOX_EALIGN,
+             "linear_residual_ln: operands must be 16-byte aligned");
+  RowLnParams p{(const bf16_t*)a, (const bf16_t*)w, bias, residual, x_out, gamma, beta, y, mean, rstd, M, K, eps};
+  const unsigned tiles = (unsigned)ceil_div(M, (int64_t)RL_BM);
+  hipStream_t st = as_stream(stream);
+  if (y_dtype == DINOX_BF16) {
+    if (int rc = reserve_lds(reinterpret_cast<const void*>(gemm_bf16_rowln<DINOX_BF16>), RL_LDS, "linear_residual_ln")) return rc;
+    hipLaunchKernelGGL(gemm_bf16_rowln<DINOX_BF16>, dim3(tiles), dim3(512), RL_LDS, st, p);
+  } else {
+    if (int rc = reserve_lds(reinterpret_cast<const void*>(gemm_bf16_rowln<DINOX_F32>), RL_LDS, "linear_residual_ln")) return rc;
+    hipLaunchKernelGGL(gemm_bf16_rowln<DINOX_F32>, dim3(tiles), dim3(512), RL_LDS, st, p);
+  }
+  return check_launch("linear_residual_ln");
+}

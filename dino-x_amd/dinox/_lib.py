@@ -45,6 +45,8 @@ SIGNATURES = {
     "dinox_colsum": (i32, [vp, vp, i64, i64, i64, i32, i32, vp]),
     "dinox_mlp_fwd_fused_ok": (i32, [i32, i32]),
     "dinox_mlp_fwd_fused": (i32, [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
+    "dinox_linear_residual_ln_ok": (i32, [i64, i32, i32]),
+    "dinox_linear_residual_ln": (i32, [vp, vp, vp, vp, vp, vp, vp, f32, vp, i32, vp, vp, i64, i32, i32, vp]),
     "dinox_layernorm_fwd": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, f32, i32, vp]),
     "dinox_layernorm_bwd_ws_bytes": (i64, [i64, i32]),
     "dinox_layernorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]),

@@ -376,6 +376,36 @@ def layernorm_fwd(x: Tensor, w: Tensor, b: Tensor, out_dtype: torch.dtype, eps: 
     return y, mean, rstd
 
 
+def rowln_ok(M: int, N: int, K: int, dt: torch.dtype) -> bool:
+    """Should this product + the LayerNorm behind it run as ONE launch (csrc/gemm_bf16_rowln.hip; bf16 mode, N = 384)?
+    OPT-IN (DINOX_ROWLN=1).  Measured on MI355X at the hot-path shape (M = 102 912): proj + LN 164 us fused against 89 + 50 us for
+    the two launches, fc2 + LN 280 us against 197 + 50; whole step 44.25 ms against 42.11 ms.  The fused kernel moves 20 % fewer
+    bytes but its row-per-lane epilogue reaches HBM in 16-byte pieces (ablation: 49 us of the 164 are the residual loads alone),
+    and its two-slot 128 x 384 K loop is slower than the 128 x 128 kernels' at K = 1536 (185 us with no epilogue traffic at all)."""
+    return dt == torch.bfloat16 and bool(os.environ.get("DINOX_ROWLN")) and bool(lib.dinox_linear_residual_ln_ok(M, N, K))
+
+
+def linear_residual_ln(a: Tensor, w: Tensor, bias: Optional[Tensor], residual: Optional[Tensor], gamma: Tensor, beta: Tensor, eps: float,
+                       y_dtype: torch.dtype):
+    """x = residual + a W^T + bias (fp32) and y = LayerNorm(x) (y_dtype) with its row statistics, one launch.
+    a [M,K] bf16, w [N,K] bf16.  Returns (x, y, mean, rstd)."""
+    _need_cuda(a, w)
+    assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and a.is_contiguous() and w.is_contiguous()
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and (residual is None or (residual.dtype == torch.float32 and residual.is_contiguous() and residual.numel() == M * N))
+    dev = a.device
+    x = torch.empty((M, N), dtype=torch.float32, device=dev)
+    y = torch.empty((M, N), dtype=y_dtype, device=dev)
+    mean = torch.empty(M, dtype=torch.float32, device=dev)
+    rstd = torch.empty(M, dtype=torch.float32, device=dev)
+    if TRACE_KERNELS is not None:
+        TRACE_KERNELS.append("gemm_bf16_rowln")
+    check(lib.dinox_linear_residual_ln(_p(a), _p(w), _p(bias), _p(residual), _p(x), _p(_c(gamma)), _p(_c(beta)), eps, _p(y), _code(y_dtype),
+                                       _p(mean), _p(rstd), M, N, K, _stream()), "dinox_linear_residual_ln")
+    return x, y, mean, rstd
+
+
 def layernorm_bwd(dy: Tensor, x: Tensor, w: Tensor, mean: Tensor, rstd: Tensor, dx: Optional[Tensor] = None,
                   dx_add: Optional[Tensor] = None, want_lowp=False, b: Optional[Tensor] = None):
     """dx = (dx_add or 0) + LN'(dy); returns (dx, dw, db, bf16 copy of dx or None).  dx may alias dx_add.
@@ -448,6 +478,29 @@ class LayerNormFn(torch.autograd.Function):
         if lowp is not None:
             lowp_cache.put(dx, lowp)
         return dx, dw, db, None, None
+
+
+class LayerNormPrecomputedFn(torch.autograd.Function):
+    """The model's final LayerNorm when its forward was already produced by the last block's fused fc2 epilogue
+    (linear_residual_ln): hands the precomputed output to autograd; backward is the ordinary LayerNorm backward."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, y, mean, rstd):
+        ctx.save_for_backward(x, w, mean, rstd, b)
+        ctx.mode_bf16 = current_dtype() == torch.bfloat16
+        if ctx.needs_input_grad[1]:
+            grad_sink.use(w, b)
+        return y.view_as(y)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, mean, rstd, b = ctx.saved_tensors
+        dx, dw, db, lowp = layernorm_bwd(dy, x.reshape(-1, x.shape[-1]), w, mean, rstd, want_lowp=ctx.mode_bf16,
+                                         b=b if ctx.needs_input_grad[1] else None)
+        dx = dx.view(x.shape)
+        if lowp is not None:
+            lowp_cache.put(dx, lowp.view(x.shape))
+        return dx, dw, db, None, None, None
 
 
 class _LowpCache:
@@ -577,34 +630,58 @@ class BlockFn(torch.autograd.Function):
     LayerNorm backward kernel, bias gradients ride along the dW products."""
 
     @staticmethod
-    def forward(ctx, x0, n1w, n1b, wqkv, bqkv, wproj, bproj, n2w, n2b, w1, b1, w2, b2, heads, eps):
+    def forward(ctx, x0, n1w, n1b, wqkv, bqkv, wproj, bproj, n2w, n2b, w1, b1, w2, b2, heads, eps, pre_ln=None, next_ln=None):
+        """``pre_ln`` = (norm1(x0), mean, rstd) when the producer of x0 already normalised it (the previous block's fc2 epilogue);
+        ``next_ln`` = (gamma, beta, eps, out_dtype) of the LayerNorm that FOLLOWS this block (the next block's norm1, or the model's
+        final norm): then the block also returns (LN(x2), mean, rstd) -- in bf16 mode at width 384 straight from the fc2 product's
+        epilogue (linear_residual_ln), as the proj product's epilogue produces norm2(x1); otherwise from LayerNorm launches.
+        Returns x2, or (x2, y_next, mean_next, rstd_next) with ``next_ln``."""
         _need_cuda(x0, wqkv)
         dt = current_dtype()
         x0 = _c(x0 if x0.dtype == torch.float32 else x0.float())
         V, N, D = x0.shape
         M = V * N
         train = any(ctx.needs_input_grad)
-        xn1, mean1, rstd1 = layernorm_fwd(x0, n1w, n1b, dt, eps)
+        if pre_ln is None:
+            xn1, mean1, rstd1 = layernorm_fwd(x0, n1w, n1b, dt, eps)
+        else:
+            xn1, mean1, rstd1 = pre_ln
         qkv = gemm(xn1.view(M, D), weight_operand(wqkv, dt), bias=bqkv, out_dtype=dt)
         o, lse = attention_fwd(qkv.view(V, N, 3 * D), heads)
-        x1 = gemm(o.view(M, D), weight_operand(wproj, dt), bias=bproj, residual=x0.view(M, D), out_dtype=torch.float32)
-        xn2, mean2, rstd2 = layernorm_fwd(x1, n2w, n2b, dt, eps)
+        if rowln_ok(M, D, D, dt):
+            x1, xn2, mean2, rstd2 = linear_residual_ln(o.view(M, D), weight_operand(wproj, dt), bproj, x0.view(M, D), n2w, n2b, eps, dt)
+        else:
+            x1 = gemm(o.view(M, D), weight_operand(wproj, dt), bias=bproj, residual=x0.view(M, D), out_dtype=torch.float32)
+            xn2, mean2, rstd2 = layernorm_fwd(x1, n2w, n2b, dt, eps)
+        nxt = None
         if (not train and dt == torch.bfloat16 and b1 is not None and b2 is not None and mlp_fused_ok(D, w1.shape[0])):
             # nothing is saved for a backward (EMA teacher, inference): the hidden activation stays on chip
             x2 = mlp_fwd_fused(xn2, weight_operand(w1, dt), b1, weight_operand(w2, dt), b2, x1)
-            return x2.view(V, N, D)
-        pre = torch.empty((M, w1.shape[0]), dtype=dt, device=x0.device) if train else None
-        act = gemm(xn2, weight_operand(w1, dt), bias=b1, gelu=True, aux=pre, auxgrad=True, out_dtype=dt)   # pre := gelu'(fc1 out)
-        x2 = gemm(act, weight_operand(w2, dt), bias=b2, residual=x1, out_dtype=torch.float32)
-        if train:
-            ctx.save_for_backward(x0, x1, xn1, xn2, qkv, o, lse, pre, act, mean1, rstd1, mean2, rstd2, n1w, n2w, wqkv, wproj, w1, w2,
-                                  bqkv, bproj, b1, b2, n1b, n2b)
-            ctx.dt, ctx.heads, ctx.shape = dt, heads, (V, N, D)
-            grad_sink.use(wqkv, bqkv, wproj, bproj, w1, b1, w2, b2, n1w, n1b, n2w, n2b)
-        return x2.view(V, N, D)
+        else:
+            H = w1.shape[0]
+            pre = torch.empty((M, H), dtype=dt, device=x0.device) if train else None
+            act = gemm(xn2, weight_operand(w1, dt), bias=b1, gelu=True, aux=pre, auxgrad=True, out_dtype=dt)   # pre := gelu'(fc1 out)
+            if next_ln is not None and rowln_ok(M, D, H, dt):
+                x2, yn, mn, rn = linear_residual_ln(act, weight_operand(w2, dt), b2, x1, next_ln[0], next_ln[1], next_ln[2], next_ln[3] or dt)
+                nxt = (yn.view(V, N, D), mn, rn)
+            else:
+                x2 = gemm(act, weight_operand(w2, dt), bias=b2, residual=x1, out_dtype=torch.float32)
+            if train:
+                ctx.save_for_backward(x0, x1, xn1, xn2, qkv, o, lse, pre, act, mean1, rstd1, mean2, rstd2, n1w, n2w, wqkv, wproj, w1, w2,
+                                      bqkv, bproj, b1, b2, n1b, n2b)
+                ctx.dt, ctx.heads, ctx.shape = dt, heads, (V, N, D)
+                grad_sink.use(wqkv, bqkv, wproj, bproj, w1, b1, w2, b2, n1w, n1b, n2w, n2b)
+        x2 = x2.view(V, N, D)
+        if next_ln is None:
+            return x2
+        if nxt is None:
+            yn, mn, rn = layernorm_fwd(x2, next_ln[0], next_ln[1], next_ln[3] or dt, next_ln[2])
+            nxt = (yn, mn, rn)
+        ctx.mark_non_differentiable(*nxt)
+        return (x2,) + nxt
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, *_unused):
         (x0, x1, xn1, xn2, qkv, o, lse, pre, act, mean1, rstd1, mean2, rstd2, n1w, n2w, wqkv, wproj, w1, w2, bqkv, bproj, b1, b2,
          n1b, n2b) = ctx.saved_tensors
         dt, heads = ctx.dt, ctx.heads
@@ -640,7 +717,7 @@ class BlockFn(torch.autograd.Function):
         g0 = g0.view(V, N, D)
         if g0_lp is not None:
             lowp_cache.put(g0, g0_lp.view(V, N, D))
-        return g0, dn1w, dn1b, dwq, dbq, dwp, dbp, dn2w, dn2b, dw1, db1, dw2, db2, None, None
+        return g0, dn1w, dn1b, dwq, dbq, dwp, dbp, dn2w, dn2b, dw1, db1, dw2, db2, None, None, None, None
 
 
 class LinearFn(torch.autograd.Function):

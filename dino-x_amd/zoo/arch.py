@@ -110,6 +110,17 @@ class TransformerBlock(nn.Module):
                 and type(a.qkv) is Linear and type(a.proj) is Linear and type(m.fc1) is Linear and type(m.fc2) is Linear
                 and self.norm1.eps == self.norm2.eps)
 
+    def forward_chained(self, x: torch.Tensor, pre_ln, next_norm: "LayerNorm", next_dtype=None):
+        """The block as one autograd node that takes norm1(x) from the producer of x (``pre_ln`` = (y, mean, rstd) or None) and
+        also returns ``next_norm`` applied to its output -- in bf16 mode at width 384 both LayerNorms of the chain come out of the
+        proj / fc2 products' epilogues (ops.linear_residual_ln) instead of separate launches.  -> (x_out, (y, mean, rstd))."""
+        a, m = self.attn, self.mlp
+        nl = (next_norm.weight.detach(), next_norm.bias.detach(), next_norm.eps, next_dtype)
+        out = ops.BlockFn.apply(x, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias,
+                                self.norm2.weight, self.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias,
+                                a.num_heads, self.norm1.eps, pre_ln, nl)
+        return out[0], (out[1], out[2], out[3])
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if self._fusable():      # the whole block as ONE autograd node (ops.BlockFn); weights are read from the sub-modules
             a, m = self.attn, self.mlp
@@ -219,6 +230,17 @@ class PatchViT(nn.Module):
         if g * g != pos.shape[1] - 1:       # extension (multi-crop local views): the reference has one input size only
             pos = ops.interp_pos(pos, g)
         t = ops.TokensFn.apply(x, self.patch_embed.weight, self.patch_embed.bias, self.cls_token, pos, regs, scale, self.patch)
+        chain = (not (self.use_grad_checkpoint and self.training) and type(self.norm) is LayerNorm and len(self.blocks) > 0
+                 and all(type(b) is TransformerBlock and b._fusable() for b in self.blocks)
+                 and all(b.norm1.eps == self.norm.eps for b in self.blocks))
+        if chain:
+            # every LayerNorm but the first rides in the epilogue of the product that wrote its input: block i hands
+            # norm1_{i+1}(x) to block i + 1, the last block hands over the final norm (fp32: the features)
+            pre = None
+            for i, blk in enumerate(self.blocks):
+                last = i + 1 == len(self.blocks)
+                t, pre = blk.forward_chained(t, pre, self.norm if last else self.blocks[i + 1].norm1, torch.float32 if last else None)
+            return ops.LayerNormPrecomputedFn.apply(t, self.norm.weight, self.norm.bias, *pre)
         for blk in self.blocks:
             if self.use_grad_checkpoint and self.training:
                 t = torch.utils.checkpoint.checkpoint(blk, t, use_reentrant=False, context_fn=ops.checkpoint_contexts)

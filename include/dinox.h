@@ -117,6 +117,22 @@ int dinox_mlp_fwd_fused(const void* xn, const void* w1, const float* b1, const v
                         const float* residual, float* out, int64_t M, int D, int H, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Linear + residual + LayerNorm in one launch (bf16 mode, model width N = 384) -- replaces, inside a pre-norm block
+ * (zoo/arch.py:94-97), the tail of one sub-block and the head of the next:
+ *     x_out = residual + a W^T + bias          (proj :53 / fc2 :76 and the residual add :95 / :96; fp32 residual stream)
+ *     y     = LayerNorm(x_out; gamma, beta)    (the following norm2 / next block's norm1 / final norm :96,:95,:237)
+ * a: [M,K] bf16, w: [N,K] bf16 (nn.Linear layout), bias [N] or NULL, residual [M,N] fp32 or NULL; x_out [M,N] fp32;
+ * y [M,N] in y_dtype (DINOX_BF16 when it feeds the next GEMM, DINOX_F32 for the model's final norm); mean, rstd [M]
+ * (biased variance, what dinox_layernorm_bwd consumes).  One workgroup owns 128 complete rows, so the residual stream is
+ * not read back by a separate LayerNorm launch.  dinox_linear_residual_ln_ok tells whether the fused kernel takes a shape
+ * (N == 384, K % 32 == 0); otherwise use dinox_gemm + dinox_layernorm_fwd.
+ * ------------------------------------------------------------------------------------------ */
+int dinox_linear_residual_ln_ok(int64_t M, int N, int K);
+int dinox_linear_residual_ln(const void* a, const void* w, const float* bias, const float* residual, float* x_out,
+                             const float* gamma, const float* beta, float eps, void* y, int y_dtype, float* mean,
+                             float* rstd, int64_t M, int N, int K, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * LayerNorm -- replaces nn.LayerNorm(D), eps 1e-5, affine (zoo/arch.py:89,91,126,187; calls :95,96,237).
  * x is the fp32 residual stream; y is written in out_dtype (bf16 when it only feeds a GEMM).
  * bwd: dx = (dx_add ? dx_add : 0) + LN'(dy)  -- dx_add is the gradient arriving over the skip connection of the

@@ -1165,38 +1165,41 @@ def test_gemm_nt_areg(dx, M, N, K, monkeypatch):
     close(d3, ref * gelu_grad(auxf.double().cpu()), 1e-4, 1e-3, "GELU' from an fp32 side tensor, fp32 out")
 
 
-@pytest.mark.parametrize("M,N,K", [(1000, 1152, 384), (128 * 9 + 5, 1536, 384), (40, 768, 384), (4096, 1536, 576), (128 * 300, 1152, 384)])
-def test_gemm_nt_wide(dx, M, N, K, monkeypatch):
-    """The opt-in 128 x 384-tile form of the wide short-K products (csrc/gemm_bf16_wide.hip, DINOX_NT_WIDE=1): plain + bias, GELU with
-    either side tensor, GELU' from either side tensor, ragged M (including a wave whose rows are all past M), against fp64 on the same
-    bf16 operands."""
+@pytest.mark.parametrize("M,K,res,bias", [(1000, 384, True, True), (128 * 5 + 17, 1536, True, True), (77, 384, True, False), (128 * 3 + 70, 384, False, True),
+                                          (4096, 1152, True, True), (128 * 700 + 9, 384, True, True)])
+@pytest.mark.parametrize("ydt", [torch.bfloat16, torch.float32])
+def test_linear_residual_ln(dx, M, K, res, bias, ydt):
+    """dinox_linear_residual_ln (csrc/gemm_bf16_rowln.hip: x = residual + a W^T + bias and y = LayerNorm(x) with the row statistics in
+    one launch, width 384) against fp64 on the same bf16 operands: x to fp32 accumulation accuracy, mean / rstd / y to LayerNorm
+    accuracy; ragged M (a last tile whose second row-wave is entirely past M), no residual, no bias, a row offset that makes
+    E[x^2] - mean^2 cancel (|mean| >> std), both output dtypes; and bit-repeatable."""
     ops, _ = dx
-    monkeypatch.setenv("DINOX_NT_WIDE", "1")
-    g = torch.Generator().manual_seed(M + N + K)
-    A, B = (torch.randn(M, K, generator=g) * 0.5).bfloat16(), (torch.randn(N, K, generator=g) * (6.0 / math.sqrt(K))).bfloat16()
-    bias = torch.randn(N, generator=g)
-    Ad, Bd = A.to(DEV), B.to(DEV)
-    ref = A.double() @ B.double().t()
-    ops.TRACE_KERNELS = []
-    try:
-        cb = ops.gemm(Ad, Bd, bias=bias.to(DEV))
-        aux = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
-        act = ops.gemm(Ad, Bd, bias=bias.to(DEV), gelu=True, aux=aux, auxgrad=True)
-        pre_aux = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
-        act_t = ops.gemm(Ad, Bd, bias=bias.to(DEV), gelu=True, aux=pre_aux)
-        d = ops.gemm(Ad, Bd, dgelu=True, aux=aux, auxgrad=True)
-        d2 = ops.gemm(Ad, Bd, dgelu=True, aux=pre_aux)
-        assert ops.TRACE_KERNELS == ["gemm_bf16_nt_wide"] * 5, ops.TRACE_KERNELS
-    finally:
-        ops.TRACE_KERNELS = None
-    erf = lambda t: torch.erf(t / math.sqrt(2))
-    gelu_grad = lambda t: 0.5 * (1 + erf(t)) + t * torch.exp(-0.5 * t * t) / math.sqrt(2 * math.pi)
-    pre = ref + bias.double()
-    assert rel_l2(cb.float(), pre) < 3e-3
-    assert rel_l2(act.float(), 0.5 * pre * (1 + erf(pre))) < 3e-3 and rel_l2(aux.float(), gelu_grad(pre)) < 3e-3
-    assert rel_l2(act_t.float(), 0.5 * pre * (1 + erf(pre))) < 3e-3 and rel_l2(pre_aux.float(), pre) < 3e-3
-    assert rel_l2(d.float(), ref * aux.float().double().cpu()) < 3e-3
-    assert rel_l2(d2.float(), ref * gelu_grad(pre_aux.float().double().cpu())) < 3e-3
+    N = 384
+    g = torch.Generator().manual_seed(M + K)
+    A, W = (torch.randn(M, K, generator=g) * 0.5).bfloat16(), (torch.randn(N, K, generator=g) * (3.0 / math.sqrt(K))).bfloat16()
+    b = torch.randn(N, generator=g) if bias else None
+    R = (torch.randn(M, N, generator=g) * 2 + 30.0 * torch.randn(M, 1, generator=g)) if res else None       # rows with a large common offset
+    gamma, beta = 1 + 0.2 * torch.randn(N, generator=g), 0.3 * torch.randn(N, generator=g)
+    import dinox._lib as L_
+    assert L_.lib.dinox_linear_residual_ln_ok(M, N, K) == 1
+    dev = lambda t_: None if t_ is None else t_.to(DEV)
+    x, y, mean, rstd = ops.linear_residual_ln(dev(A), dev(W), dev(b), dev(R), dev(gamma), dev(beta), 1e-5, ydt)
+    x2, y2, mean2, rstd2 = ops.linear_residual_ln(dev(A), dev(W), dev(b), dev(R), dev(gamma), dev(beta), 1e-5, ydt)
+    assert torch.equal(x, x2) and torch.equal(y, y2) and torch.equal(mean, mean2) and torch.equal(rstd, rstd2)
+    xr = A.double() @ W.double().t() + (b.double() if bias else 0) + (R.double() if res else 0)
+    mu = xr.mean(-1, keepdim=True)
+    var = ((xr - mu) ** 2).mean(-1, keepdim=True)
+    yr = (xr - mu) / torch.sqrt(var + 1e-5) * gamma.double() + beta.double()
+    assert x.shape == (M, N) and x.dtype == torch.float32 and y.dtype == ydt
+    close(x, xr, 2e-6, 1e-5, "x")
+    close(mean, mu.reshape(-1), 2e-6, 1e-5, "mean")
+    assert rel_l2(rstd, 1 / torch.sqrt(var + 1e-5).reshape(-1)) < 1e-5
+    assert rel_l2(y.float(), yr) < (4e-3 if ydt == torch.bfloat16 else 2e-5)
+    # and against the two launches it replaces, on the device
+    xg = ops.gemm(dev(A), dev(W), bias=dev(b), residual=dev(R), out_dtype=torch.float32)
+    yg, mg, rg = ops.layernorm_fwd(xg, dev(gamma), dev(beta), ydt, 1e-5)
+    close(x, xg, 1e-6, 1e-5, "x vs gemm")
+    assert rel_l2(y.float(), yg.float()) < (4e-3 if ydt == torch.bfloat16 else 2e-5) and rel_l2(rstd, rg) < 1e-5
 
 
 def test_gemm_nt_store_policy_is_only_a_hint(dx, monkeypatch):

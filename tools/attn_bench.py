@@ -1,24 +1,31 @@
 #!/usr/bin/env python3
-"""Micro-benchmark of the attention kernels at the hot-path shape (B=512 views, N=201, 6 heads, d=64, bf16)."""
+"""Micro-benchmark of the attention kernels at the hot-path shape (ViT-S/16 bs256: 512 views x 6 heads x 201 tokens x 64).
+HIP-event timing, interleaved rounds, random data.  DINOX_ATTN_BWD_SPLIT=1 times the two-kernel backward."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "dino-x_amd")]
 import torch
 from dinox import ops
-B, N, H, D = int(os.environ.get("B", 512)), int(os.environ.get("N", 201)), 6, 64
-g = torch.Generator(device="cuda").manual_seed(0)
-qkv = torch.randn(B, N, 3 * H * D, device="cuda", generator=g).bfloat16()
-do = torch.randn(B, N, H * D, device="cuda", generator=g).bfloat16()
+
+V, N, H = int(os.environ.get("V", 512)), int(os.environ.get("N", 201)), int(os.environ.get("H", 6))
+dev = "cuda"
+g = torch.Generator(device=dev).manual_seed(0)
+qkv = (torch.randn(V, N, 3 * H * 64, device=dev, generator=g) * 0.7).bfloat16()
+do = (torch.randn(V, N, H * 64, device=dev, generator=g) * 0.1).bfloat16()
 o, lse = ops.attention_fwd(qkv, H)
-def t(fn, n=10):
-    for _ in range(3): fn()
-    torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
-    for a, b in ev:
-        a.record(); fn(); b.record()
-    torch.cuda.synchronize()
-    ts = sorted(a.elapsed_time(b) * 1e3 for a, b in ev)
-    return ts[len(ts) // 2], ts[0]
-f = 4.0 * B * H * N * N * D
-m, lo = t(lambda: ops.attention_fwd(qkv, H)); print(f"attn fwd  med {m:7.1f} us min {lo:7.1f} us  {f / m / 1e6:6.1f} TFLOP/s (alg)")
-m, lo = t(lambda: ops.attention_bwd(do, qkv, o, lse, H)); print(f"attn bwd  med {m:7.1f} us min {lo:7.1f} us  {2.5 * f / m / 1e6:6.1f} TFLOP/s (alg, 5 products)")
+cases = {"fwd": lambda: ops.attention_fwd(qkv, H), "bwd": lambda: ops.attention_bwd(do, qkv, o, lse, H)}
+for f in cases.values():
+    for _ in range(3): f()
+torch.cuda.synchronize()
+times = {n: [] for n in cases}
+for r in range(int(os.environ.get("ROUNDS", 10))):
+    for n, f in cases.items():
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); f(); e1.record()
+        times[n].append((e0, e1))
+torch.cuda.synchronize()
+el = V * N * H * 64 * 2
+byt = {"fwd": 4 * el, "bwd": 8 * el}          # q,k,v in + o out ; q,k,v,dO,O in + dq,dk,dv out
+for n in cases:
+    ts = sorted(a.elapsed_time(b) * 1e3 for a, b in times[n])
+    print(f"attention {n} V={V} N={N} h={H}: med {ts[len(ts)//2]:7.1f} us  min {ts[0]:7.1f} us   {byt[n] / ts[len(ts)//2] / 1e6:5.2f} TB/s (every tensor once)")

@@ -32,6 +32,10 @@ case("fc2   NT K1536 N384 bias+res f32", lambda: ops.gemm(xh, w2, bias=bd, resid
 case("dact  NT K384 N1536 dgelu        ", lambda: ops.gemm(x, w2T, dgelu=True, aux=pre, auxgrad=True), 2 * M * D * H, M * D * 2 + 2 * M * H * 2)
 case("dxn2  NT K1536 N384 plain        ", lambda: ops.gemm(xh, w1T), 2 * M * D * H, M * H * 2 + M * D * 2)
 case("dxn1  NT K1152 N384 plain        ", lambda: ops.gemm(x3, wqkvT), 2 * M * D * 3 * D, M * 3 * D * 2 + M * D * 2)
+gam, bet = rf(D), rf(D)
+case("projLN rowln K384 +res +LN->bf16 ", lambda: ops.linear_residual_ln(x, wproj, bd, res, gam, bet, 1e-5, torch.bfloat16), 2 * M * D * D, M * D * 2 + 2 * M * D * 4 + M * D * 2)
+case("fc2LN  rowln K1536 +res +LN->bf16", lambda: ops.linear_residual_ln(xh, w2, bd, res, gam, bet, 1e-5, torch.bfloat16), 2 * M * D * H, M * H * 2 + 2 * M * D * 4 + M * D * 2)
+case("ln_fwd 384 fp32 -> bf16          ", lambda: ops.layernorm_fwd(res, gam, bet, torch.bfloat16), 8 * M * D, M * D * 4 + M * D * 2)
 db = torch.empty(H, device=dev)
 case("dW1   TN M1536 N384  (+db)       ", lambda: ops.gemm(xh, x, transA=True, transB=True, out_dtype=torch.float32, colsum_out=db), 2 * M * D * H, M * H * 2 + M * D * 2)
 dbq = torch.empty(3 * D, device=dev)

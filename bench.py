@@ -105,6 +105,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short measurements of the other single-GPU configs")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket GEMM launches with HIP events")
+    ap.add_argument("--no-step-split", action="store_true", help="skip the extra steps that time the phases of the step (profiler runs)")
     return ap.parse_args(argv)
 
 
@@ -276,7 +277,7 @@ def main() -> None:
     if not (scal["loss"] == scal["loss"]):
         raise SystemExit("non-finite loss in the timed region")
     kernels = timer.summary() if timer else {}
-    split = wl.step_split() if not args.graph else None     # (every rank: the step holds collectives)
+    split = wl.step_split() if not (args.graph or args.no_step_split) else None     # (every rank: the step holds collectives)
     overlapped = getattr(wl.eng.bucketer, "fired_in_backward", None)
 
     if rank == 0:

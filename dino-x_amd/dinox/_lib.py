@@ -43,8 +43,6 @@ SIGNATURES = {
     "dinox_gemm": (i32, [C.POINTER(GemmArgs), vp]),
     "dinox_gemm_kernel_name": (C.c_char_p, [C.POINTER(GemmArgs)]),
     "dinox_colsum": (i32, [vp, vp, i64, i64, i64, i32, i32, vp]),
-    "dinox_mlp_fwd_fused_ok": (i32, [i32, i32]),
-    "dinox_mlp_fwd_fused": (i32, [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
     "dinox_linear_residual_ln_ok": (i32, [i64, i32, i32]),
     "dinox_linear_residual_ln": (i32, [vp, vp, vp, vp, vp, vp, vp, f32, vp, i32, vp, vp, i64, i32, i32, vp]),
     "dinox_layernorm_fwd": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, f32, i32, vp]),
@@ -77,6 +75,11 @@ SIGNATURES = {
     "dinox_cast_bf16": (i32, [vp, vp, i64, vp]),
     "dinox_cast_transpose_bf16": (i32, [vp, vp, i32, i32, vp]),
     "dinox_cast_transpose_bf16_multi": (i32, [vp, vp, vp, i32, i64, vp]),
+    "dinox_take_rows": (i32, [vp, vp, i64, i64, i32, i64, i32, vp]),
+    "dinox_put_rows": (i32, [vp, vp, i64, i64, i32, i64, i32, i32, vp]),
+    "dinox_axpy": (i32, [vp, vp, f32, i64, vp]),
+    "dinox_lincomb3": (i32, [vp, vp, vp, f32, f32, vp, vp]),
+    "dinox_zero": (i32, [vp, i64, vp]),
     "dinox_gelu_fwd": (i32, [vp, vp, i64, vp]),
     "dinox_gelu_bwd": (i32, [vp, vp, vp, i64, vp]),
 }

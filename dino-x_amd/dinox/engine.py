@@ -122,6 +122,11 @@ class TrainEngine:
         self._eager_steps = 0
         self._hyper_dev = torch.zeros(3, dtype=torch.float32, device=dev)
         self._hyper_host = torch.zeros(3, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(3)
+        import zoo.arch as _arch
+        self.manual_top = all(type(m.head) is _arch.DinoHead and type(m.head[0]) is _arch.Linear and type(m.head[2]) is _arch.Linear
+                              and m.head[0].bias is not None and m.head[2].bias is not None for m in (student, teacher)) \
+            and not os.environ.get("DINOX_AUTOGRAD_TOP")
+        self._zero1 = torch.zeros(1, dtype=torch.float32, device=dev)
         self.marks = None            # bench.py: a list -> (phase name, HIP event on the launch stream) at every phase boundary of step()
         self.step_count = 0          # micro-batches seen (drives the LR schedule, like the reference)
         self.opt_steps = 0           # optimiser steps taken (AdamW bias correction)
@@ -184,7 +189,7 @@ class TrainEngine:
         last = (self.step_count + 1) % self.accum == 0
         self._mark("start")
         if first:
-            self.flat_g.zero_()
+            ops.zero_(self.flat_g)
         self.bucketer.active = last
         self.bucketer.arm()
         if ops.grad_sink.owner is not self:      # weight gradients accumulate straight into flat_g (ops._GradSink)
@@ -201,47 +206,26 @@ class TrainEngine:
                 side.wait_stream(main)
                 with torch.cuda.stream(side), torch.no_grad():
                     t_feats = self.teacher.backbone(batch, spacing=spacing2b)
-                    t_out = self.teacher.head(t_feats[:, 0])
                 s_feats = self.student.backbone(batch, spacing=spacing2b)
                 main.wait_stream(side)
                 t_feats.record_stream(main)
-                t_out.record_stream(main)
             else:
                 s_feats = self.student.backbone(batch, spacing=spacing2b)
                 self._mark("fwd_student")
                 with torch.no_grad():
                     t_feats = self.teacher.backbone(batch, spacing=spacing2b)
-                    t_out = self.teacher.head(t_feats[:, 0])
                 self._mark("fwd_teacher")
-            if local_batch is None:
-                s_out = self.student.head(s_feats[:, 0])
-                l_dino = ops.DinoCEFn.apply(s_out, t_out, self.center, hp.student_temp, hp.teacher_temp)
+            if self.manual_top:
+                loss, l_dino, l_gram, l_koleo, bm, bm_work = self._losses_and_backward(s_feats, t_feats, batch, local_batch, local_spacing)
             else:
-                l_feats = self.student.backbone(local_batch, spacing=local_spacing)
-                s_all = self.student.head(torch.cat([s_feats[:, 0], l_feats[:, 0]], 0))       # one head product for all views
-                s_out = s_all[:s_feats.shape[0]]
-                l_dino = ops.DinoCEMultiFn.apply(s_all, t_out, self.center, hp.student_temp, hp.teacher_temp, 2)
-            # centre EMA after the loss used the old centre; batch mean is global under DP
-            bm = ops.colmean(t_out)
-            bm_work = dist.all_reduce(bm, op=dist.ReduceOp.SUM, group=self.group, async_op=True) if exchanging(self.group) else None
-            # (the centre itself moves after backward: the loss used the old centre, so the exchange can run under the backward pass)
-            if hp.gram_weight != 0.0:
-                l_gram = ops.GramLossFn.apply(s_feats, t_feats)
-                loss = l_dino + hp.gram_weight * l_gram
-            else:
-                l_gram = torch.zeros((), device=batch.device)
-                loss = l_dino
-            if hp.koleo_weight > 0.0:                        # :1764-1766; nearest neighbours over the global batch under DP
-                l_koleo = ops.koleo_loss(s_out, group=self.group)
-                loss = loss + hp.koleo_weight * l_koleo
-            else:
-                l_koleo = torch.zeros((), device=batch.device)
-            self._mark("loss")            # (local-crop forward, student head, DINO CE, Gram, KoLeo forward)
-            (loss if self.accum == 1 else loss / self.accum).backward()
+                with torch.no_grad():
+                    t_out = self.teacher.head(t_feats[:, 0])
+                loss, l_dino, l_gram, l_koleo, bm, bm_work = self._losses_and_backward_autograd(s_feats, t_feats, t_out, batch, local_batch,
+                                                                                                local_spacing)
         self._mark("bwd")
         if bm_work is not None:
             bm_work.wait()
-            bm.div_(self.world)
+            bm.div_(self.world)           # (data parallel only)
         ops.center_ema_(self.center.view(-1), bm, hp.center_momentum)
         self.bucketer.finish()
         self._mark("comm_exposed")        # what of the exchanges did not fit under backward (+ the centre EMA launch)
@@ -255,12 +239,135 @@ class TrainEngine:
                 for sh in self.shadows:  # one cast launch per arena (+ one for every transposed matrix backward uses)
                     sh.refresh()
         else:
-            gsq = torch.zeros(1, device=batch.device)       # the reference logs grad-norm 0 between optimiser steps
+            gsq = self._zero1                                # the reference logs grad-norm 0 between optimiser steps
         self._mark("optimiser_tail")
         self.step_count += 1
         self.last = {"loss": loss.detach(), "dino": l_dino.detach(), "gram": l_gram.detach(), "koleo": l_koleo.detach(),
                      "grad_norm_sq": gsq, "lr": lr}
         return self.last
+
+    # -- everything above the backbones, without the framework's elementwise kernels ---------------------------------
+    def _head_forward(self, head, cls_op: torch.Tensor, train: bool):
+        """DinoHead = Linear(D,D) -> GELU -> Linear(D,out) (zoo/arch.py:252-256) on the CLS rows: two products, GELU (and GELU' for the
+        backward) in the first one's epilogue.  Returns (logits fp32, saved)."""
+        dt = self.compute_dtype
+        l0, l2 = head[0], head[2]
+        pre0 = torch.empty((cls_op.shape[0], l0.weight.shape[0]), dtype=dt, device=cls_op.device) if train else None
+        h0 = ops.gemm(cls_op, ops.weight_operand(l0.weight, dt), bias=l0.bias, gelu=True, aux=pre0, auxgrad=True, out_dtype=dt)
+        out = ops.gemm(h0, ops.weight_operand(l2.weight, dt), bias=l2.bias, out_dtype=torch.float32)
+        if train:
+            ops.grad_sink.use(l0.weight, l0.bias, l2.weight, l2.bias)
+        return out, (cls_op, h0, pre0)
+
+    def _head_backward(self, head, saved, ds: torch.Tensor) -> torch.Tensor:
+        """d logits [V,out] fp32 -> d CLS rows [V,D]; the four parameter gradients go straight into the gradient arena."""
+        dt = self.compute_dtype
+        l0, l2 = head[0], head[2]
+        cls_op, h0, pre0 = saved
+        dy = ops.to_mode(ds, dt)
+        if dt == torch.float32:
+            dpre = ops.gemm(dy, l2.weight.detach(), transB=True, dgelu=True, aux=pre0, auxgrad=True, out_dtype=dt)
+        else:
+            dpre = ops.gemm(dy, ops.weight_operand(l2.weight, dt, transposed=True), dgelu=True, aux=pre0, auxgrad=True, out_dtype=dt)
+        g2 = ops.weight_grad(dy, h0, l2.weight, l2.bias, True)
+        if dt == torch.float32:
+            dcls = ops.gemm(dpre, l0.weight.detach(), transB=True, out_dtype=dt)
+        else:
+            dcls = ops.gemm(dpre, ops.weight_operand(l0.weight, dt, transposed=True), out_dtype=dt)
+        g0 = ops.weight_grad(dpre, cls_op, l0.weight, l0.bias, True)
+        assert g2 == (None, None) and g0 == (None, None), "the head's parameters must live in the engine's gradient arena"
+        return dcls
+
+    def _losses_and_backward(self, s_feats, t_feats, batch, local_batch, local_spacing):
+        """Heads, DINO CE (pre-update centre), Gram, KoLeo and the gradient of their weighted sum w.r.t. the student features, written
+        out by hand -- every step is one of the library's kernels -- then ONE autograd backward from the features down.  (Through
+        autograd the same thing costs a strided CLS copy + cast per head, `ds * g` / `d * g` multiplies, a zero fill + slice copy +
+        158 MB add to merge the two feature gradients, and a handful of scalar kernels: ~0.35 ms of framework kernels per step.)"""
+        hp, dt = self.hp, self.compute_dtype
+        scale = 1.0 / self.accum
+        V = s_feats.shape[0]
+        with torch.no_grad():
+            sf = s_feats.detach()
+            t_out, _ = self._head_forward(self.teacher.head, ops.take_rows(t_feats, 0, dt), train=False)
+            if local_batch is None:
+                l_feats = None
+                cls = ops.take_rows(sf, 0, dt)
+            else:
+                with torch.enable_grad():
+                    l_feats = self.student.backbone(local_batch, spacing=local_spacing)
+                lf = l_feats.detach()
+                cls = ops.take_rows(sf, 0, dt, out_rows=V + lf.shape[0])
+                ops.take_rows(lf, 0, dt, out=cls, out_row0=V)
+            s_all, saved = self._head_forward(self.student.head, cls, train=True)
+            if local_batch is None:
+                l_dino, ds = ops.dino_ce(s_all, t_out, self.center, hp.student_temp, hp.teacher_temp, True, grad_scale=scale)
+            else:
+                l_dino, ds = ops.dino_ce_multi(s_all, t_out, self.center, hp.student_temp, hp.teacher_temp, 2, grad_scale=scale)
+            # centre EMA after the loss used the old centre; batch mean is global under DP (the centre itself moves after backward,
+            # so the exchange runs under the backward pass)
+            bm = ops.colmean(t_out)
+            bm_work = dist.all_reduce(bm, op=dist.ReduceOp.SUM, group=self.group, async_op=True) if exchanging(self.group) else None
+            l_koleo = None
+            if hp.koleo_weight > 0.0:                        # :1764-1766; nearest neighbours over the global batch under DP
+                with torch.enable_grad():
+                    xk = s_all[:V].detach().requires_grad_(True)
+                    l_koleo = ops.koleo_loss(xk, group=self.group)
+                    l_koleo.backward()
+                if local_batch is None:
+                    ops.axpy_(ds, xk.grad, hp.koleo_weight * scale)
+                else:
+                    ds[:V].add_(xk.grad, alpha=hp.koleo_weight * scale)
+                l_koleo = l_koleo.detach().reshape(1)
+            dcls = self._head_backward(self.student.head, saved, ds)
+            dfeats = torch.empty_like(sf)
+            l_gram = None
+            if hp.gram_weight != 0.0:
+                l_gram, gsaved = ops.gram_loss_fwd(sf, t_feats, dt)
+                ops.gram_loss_bwd(gsaved, tuple(sf.shape), hp.gram_weight * scale, dfeats=dfeats, accumulate=False)   # rows 1..N-1
+            else:
+                ops.zero_(dfeats)
+            ops.put_rows_(dfeats, 0, dcls)                                                                            # row 0 (CLS)
+            roots, grads = [s_feats], [dfeats]
+            if l_feats is not None:
+                dl = torch.empty_like(lf)
+                ops.zero_(dl)
+                ops.put_rows_(dl, 0, dcls, src_row0=V)
+                roots.append(l_feats)
+                grads.append(dl)
+            loss = ops.lincomb3(l_dino, l_gram, l_koleo, hp.gram_weight, hp.koleo_weight)
+        self._mark("loss")
+        torch.autograd.backward(roots, grads)
+        z = self._zero1
+        return loss.reshape(()), l_dino.reshape(()), (l_gram if l_gram is not None else z).reshape(()), \
+            (l_koleo if l_koleo is not None else z).reshape(()), bm, bm_work
+
+    def _losses_and_backward_autograd(self, s_feats, t_feats, t_out, batch, local_batch, local_spacing):
+        """The same through the per-op autograd nodes (a head whose layers were replaced, e.g. LoRA-wrapped)."""
+        hp = self.hp
+        if local_batch is None:
+            s_out = self.student.head(s_feats[:, 0])
+            l_dino = ops.DinoCEFn.apply(s_out, t_out, self.center, hp.student_temp, hp.teacher_temp)
+        else:
+            l_feats = self.student.backbone(local_batch, spacing=local_spacing)
+            s_all = self.student.head(torch.cat([s_feats[:, 0], l_feats[:, 0]], 0))       # one head product for all views
+            s_out = s_all[:s_feats.shape[0]]
+            l_dino = ops.DinoCEMultiFn.apply(s_all, t_out, self.center, hp.student_temp, hp.teacher_temp, 2)
+        bm = ops.colmean(t_out)
+        bm_work = dist.all_reduce(bm, op=dist.ReduceOp.SUM, group=self.group, async_op=True) if exchanging(self.group) else None
+        if hp.gram_weight != 0.0:
+            l_gram = ops.GramLossFn.apply(s_feats, t_feats)
+            loss = l_dino + hp.gram_weight * l_gram
+        else:
+            l_gram = torch.zeros((), device=batch.device)
+            loss = l_dino
+        if hp.koleo_weight > 0.0:
+            l_koleo = ops.koleo_loss(s_out, group=self.group)
+            loss = loss + hp.koleo_weight * l_koleo
+        else:
+            l_koleo = torch.zeros((), device=batch.device)
+        self._mark("loss")            # (local-crop forward, student head, DINO CE, Gram, KoLeo forward)
+        (loss if self.accum == 1 else loss / self.accum).backward()
+        return loss.detach(), l_dino.detach(), l_gram.detach(), l_koleo.detach(), bm, bm_work
 
     # -- convenience ------------------------------------------------------------------------------
     def scalars(self) -> dict:

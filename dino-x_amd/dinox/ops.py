@@ -343,26 +343,6 @@ def weight_operand(w: Tensor, dt: torch.dtype, transposed=False) -> Tensor:
     return weight_cache.get(w, transposed)
 
 
-def mlp_fused_ok(D: int, H: int) -> bool:
-    """Opt-in (DINOX_FUSED_MLP=1): at ViT-S sizes the fused kernel measures 534 us against 438 us for the two GEMMs it replaces
-    (one wave per SIMD exposes every per-chunk latency), so the two-GEMM path stays the default."""
-    return bool(os.environ.get("DINOX_FUSED_MLP")) and bool(lib.dinox_mlp_fwd_fused_ok(D, H))
-
-
-def mlp_fwd_fused(xn: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, residual: Tensor) -> Tensor:
-    """residual + b2 + GELU(xn W1^T + b1) W2^T in one kernel (bf16 operands, fp32 out); for passes without a backward."""
-    _need_cuda(xn, w1, w2, residual)
-    assert xn.dtype == torch.bfloat16 and w1.dtype == torch.bfloat16 and w2.dtype == torch.bfloat16
-    xn, w1, w2, residual = _c(xn), _c(w1), _c(w2), _c(residual)
-    M, D = xn.shape
-    H = w1.shape[0]
-    assert w1.shape == (H, D) and w2.shape == (D, H) and residual.shape == (M, D) and residual.dtype == torch.float32
-    out = torch.empty((M, D), dtype=torch.float32, device=xn.device)
-    check(lib.dinox_mlp_fwd_fused(_p(xn), _p(w1), _p(_c(b1)), _p(w2), _p(_c(b2)), _p(residual), _p(out), M, D, H, _stream()),
-          "dinox_mlp_fwd_fused")
-    return out
-
-
 def layernorm_fwd(x: Tensor, w: Tensor, b: Tensor, out_dtype: torch.dtype, eps: float = 1e-5):
     _need_cuda(x, w, b)
     assert x.dtype == torch.float32
@@ -604,6 +584,20 @@ def checkpoint_contexts():
     return contextlib.nullcontext(), _recompute_scope()
 
 
+def small_grad(param: Optional[Tensor], g: Optional[Tensor]) -> Optional[Tensor]:
+    """A small parameter gradient (tokens, position embedding, scale-embedding MLP) produced by a kernel as a tensor of its own:
+    with the parameter registered in the gradient sink it is added into the arena by dinox_axpy and autograd gets None (instead of
+    one framework add kernel per parameter: nine per ViT-S step)."""
+    if g is None or param is None:
+        return g
+    slot = grad_sink.lookup(param)
+    if slot is None or g.dtype != torch.float32 or not g.is_contiguous():
+        return g
+    axpy_(slot[1].grad.view(-1), g.view(-1), 1.0)
+    grad_sink.ready(slot)
+    return None
+
+
 def weight_grad(dy: Tensor, x: Tensor, w: Tensor, bias: Optional[Tensor], want_db: bool):
     """dW = dy^T x  ([N,M].[M,K]) and, if wanted, db = column sums of dy, from one product.
     Returns (dw, db) for autograd -- or (None, None) after accumulating both into the engine's gradient arena."""
@@ -637,6 +631,7 @@ class BlockFn(torch.autograd.Function):
         epilogue (linear_residual_ln), as the proj product's epilogue produces norm2(x1); otherwise from LayerNorm launches.
         Returns x2, or (x2, y_next, mean_next, rstd_next) with ``next_ln``."""
         _need_cuda(x0, wqkv)
+        ctx.set_materialize_grads(False)      # the non-differentiable outputs (LN of the next block) would otherwise arrive as zero-FILLED tensors
         dt = current_dtype()
         x0 = _c(x0 if x0.dtype == torch.float32 else x0.float())
         V, N, D = x0.shape
@@ -654,10 +649,9 @@ class BlockFn(torch.autograd.Function):
             x1 = gemm(o.view(M, D), weight_operand(wproj, dt), bias=bproj, residual=x0.view(M, D), out_dtype=torch.float32)
             xn2, mean2, rstd2 = layernorm_fwd(x1, n2w, n2b, dt, eps)
         nxt = None
-        if (not train and dt == torch.bfloat16 and b1 is not None and b2 is not None and mlp_fused_ok(D, w1.shape[0])):
-            # nothing is saved for a backward (EMA teacher, inference): the hidden activation stays on chip
-            x2 = mlp_fwd_fused(xn2, weight_operand(w1, dt), b1, weight_operand(w2, dt), b2, x1)
-        else:
+        # (A fused fc1 -> GELU -> fc2 kernel for passes that save nothing -- hidden activation on chip, -632 MB per block -- was built in
+        #  round 1 and removed in round 2: 509 us against 197 + 197 us for the two products at the hot-path shape)
+        if True:
             H = w1.shape[0]
             pre = torch.empty((M, H), dtype=dt, device=x0.device) if train else None
             act = gemm(xn2, weight_operand(w1, dt), bias=b1, gelu=True, aux=pre, auxgrad=True, out_dtype=dt)   # pre := gelu'(fc1 out)
@@ -895,7 +889,8 @@ class TokensFn(torch.autograd.Function):
         check(lib.dinox_tokens_fwd(_p(patches), _p(_c(cls)), _p(_c(pos)), _p(None if regs is None else _c(regs)), _p(sc), _p(tokens),
                                    V, P, R, D, _code(dt), _stream()), "dinox_tokens_fwd")
         ctx.save_for_backward(u, pw, pb)
-        grad_sink.use(pw, pb)
+        ctx.small = (cls, pos if isinstance(pos, torch.nn.Parameter) else None, regs)       # (an interpolated pos is not a leaf)
+        grad_sink.use(pw, pb, cls, ctx.small[1], regs)
         ctx.dims, ctx.dt, ctx.has_scale = (V, P, R, D), dt, scale is not None
         return tokens
 
@@ -914,7 +909,8 @@ class TokensFn(torch.autograd.Function):
         check(lib.dinox_tokens_bwd(_p(dtok), _p(dpatches), _p(dcls), _p(dpos), _p(dregs), _p(dscale), V, P, R, D, _code(dt), _stream()),
               "dinox_tokens_bwd")
         dw, db = weight_grad(dpatches, u, pw, pb, pb is not None)
-        return None, dw, db, dcls, dpos, dregs, dscale, None
+        cls, pos, regs = ctx.small
+        return None, dw, db, small_grad(cls, dcls), small_grad(pos, dpos), small_grad(regs, dregs), dscale, None
 
 
 class ScaleEmbedFn(torch.autograd.Function):
@@ -934,6 +930,8 @@ class ScaleEmbedFn(torch.autograd.Function):
         check(lib.dinox_scale_embed_fwd(_p(sp), _p(_c(w0)), _p(b0), _p(_c(w2)), _p(b2), _p(lnw), _p(lnb), _p(out), _p(hpre), _p(e),
                                         _p(mean), _p(rstd), V, h, D, eps, _stream()), "dinox_scale_embed_fwd")
         ctx.save_for_backward(sp, w0, w2, lnw, hpre, e, mean, rstd)
+        ctx.small = (w0, b0, w2, b2, lnw, lnb)
+        grad_sink.use(*ctx.small)
         return out
 
     @staticmethod
@@ -948,7 +946,9 @@ class ScaleEmbedFn(torch.autograd.Function):
         check(lib.dinox_scale_embed_bwd(_p(_c(dout)), _p(sp), _p(_c(w0)), _p(_c(w2)), _p(lnw), _p(hpre), _p(e), _p(mean), _p(rstd),
                                         _p(dw0), _p(db0), _p(dw2), _p(db2), _p(dlnw), _p(dlnb), _p(dsp), _p(ws), V, h, D, _stream()),
               "dinox_scale_embed_bwd")
-        return dsp, dw0, db0, dw2, db2, dlnw, dlnb, None
+        pw0, pb0, pw2, pb2, plnw, plnb = ctx.small
+        return (dsp, small_grad(pw0, dw0), small_grad(pb0, db0), small_grad(pw2, dw2), small_grad(pb2, db2), small_grad(plnw, dlnw),
+                small_grad(plnb, dlnb), None)
 
 
 def dino_ce(s: Tensor, t: Tensor, center: Tensor, student_temp: float, teacher_temp: float, want_grad: bool, grad_scale: float = 1.0):
@@ -961,6 +961,22 @@ def dino_ce(s: Tensor, t: Tensor, center: Tensor, student_temp: float, teacher_t
     ds = torch.empty_like(s) if want_grad else None
     check(lib.dinox_dino_ce(_p(s), _p(t), _p(_c(center).reshape(-1)), student_temp, teacher_temp, grad_scale, _p(loss), _p(ds), _p(row_loss),
                             rows, K, _stream()), "dinox_dino_ce")
+    return loss, ds
+
+
+def dino_ce_multi(s: Tensor, t: Tensor, center: Tensor, student_temp: float, teacher_temp: float, n_global: int, grad_scale: float = 1.0):
+    """Multi-crop DINO CE (see DinoCEMultiFn): returns (loss[1], ds) with ds already multiplied by grad_scale."""
+    _need_cuda(s, t, center)
+    sf, tf = _c(s.float()), _c(t.float())
+    K = sf.shape[1]
+    B = tf.shape[0] // n_global
+    n_views = sf.shape[0] // B
+    assert tf.shape[0] == n_global * B and sf.shape[0] == n_views * B and tf.shape[1] == K, (tuple(s.shape), tuple(t.shape), n_global)
+    loss = torch.empty(1, dtype=torch.float32, device=sf.device)
+    ds = torch.empty_like(sf)
+    ws = torch.empty((n_views + 2 * n_global) * B, dtype=torch.float32, device=sf.device)
+    check(lib.dinox_dino_ce_multi(_p(sf), _p(tf), _p(_c(center).reshape(-1)), student_temp, teacher_temp, grad_scale, _p(loss), _p(ds), _p(ws),
+                                  B, n_global, n_views, K, _stream()), "dinox_dino_ce_multi")
     return loss, ds
 
 
@@ -1066,6 +1082,41 @@ class PosInterpFn(torch.autograd.Function):
 
 def interp_pos(pos: Tensor, g_out: int) -> Tensor:
     return PosInterpFn.apply(pos, g_out)
+
+
+def take_rows(src: Tensor, row: int, dt: torch.dtype, out: Optional[Tensor] = None, out_row0: int = 0, out_rows: int = 0) -> Tensor:
+    """src [V,N,D] fp32 -> out[out_row0 + v] = src[v, row] in dt (``feats[:, 0]`` without a strided copy + cast)."""
+    _need_cuda(src)
+    assert src.dtype == torch.float32 and src.is_contiguous() and src.dim() == 3
+    V, N, D = src.shape
+    if out is None:
+        out = torch.empty((out_rows or V, D), dtype=dt, device=src.device)
+    check(lib.dinox_take_rows(src.data_ptr() + 4 * row * D, _p(out), V, N * D, D, out_row0, _code(dt), _stream()), "dinox_take_rows")
+    return out
+
+
+def put_rows_(dst: Tensor, row: int, src: Tensor, src_row0: int = 0, accumulate: bool = False) -> None:
+    """dst[v, row] (+)= src[src_row0 + v]  (dst [V,N,D] fp32; src [*,D] fp32 or bf16)."""
+    assert dst.dtype == torch.float32 and dst.is_contiguous() and dst.dim() == 3 and src.is_contiguous()
+    V, N, D = dst.shape
+    check(lib.dinox_put_rows(_p(src), dst.data_ptr() + 4 * row * D, V, N * D, D, src_row0, _code(src.dtype), int(accumulate), _stream()),
+          "dinox_put_rows")
+
+
+def axpy_(y: Tensor, x: Tensor, alpha: float) -> None:
+    assert y.dtype == torch.float32 and x.dtype == torch.float32 and y.is_contiguous() and x.is_contiguous() and y.numel() == x.numel()
+    check(lib.dinox_axpy(_p(y), _p(x), alpha, y.numel(), _stream()), "dinox_axpy")
+
+
+def lincomb3(a: Tensor, b: Optional[Tensor], c: Optional[Tensor], wb: float, wc: float) -> Tensor:
+    out = torch.empty(1, dtype=torch.float32, device=a.device)
+    check(lib.dinox_lincomb3(_p(a), _p(b), _p(c), wb, wc, _p(out), _stream()), "dinox_lincomb3")
+    return out
+
+
+def zero_(t: Tensor) -> None:
+    assert t.is_contiguous()
+    check(lib.dinox_zero(_p(t), t.numel() * t.element_size(), _stream()), "dinox_zero")
 
 
 def colmean(t: Tensor) -> Tensor:

@@ -106,17 +106,6 @@ int dinox_colsum(const void* x, float* out, int64_t M, int64_t N, int64_t ldx, i
                  void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * Fused MLP for passes without a backward (EMA teacher, inference) -- replaces Mlp.forward plus the block's
- * skip connection (zoo/arch.py:75-76, :96) in ONE kernel:  out = residual + b2 + GELU_erf(xn W1^T + b1) W2^T.
- * xn [M][D] bf16 (LayerNorm output), w1 [H][D] bf16, w2 [D][H] bf16, biases fp32, residual / out [M][D] fp32
- * (out may alias residual).  The hidden activation [M][H] never reaches HBM.  Envelope: dinox_mlp_fwd_fused_ok(D, H)
- * (D in {64,128,192,256,384}, H % 32 == 0); everything 16-byte aligned.
- * ------------------------------------------------------------------------------------------ */
-int dinox_mlp_fwd_fused_ok(int D, int H);
-int dinox_mlp_fwd_fused(const void* xn, const void* w1, const float* b1, const void* w2, const float* b2,
-                        const float* residual, float* out, int64_t M, int D, int H, void* stream);
-
-/* ------------------------------------------------------------------------------------------
  * Linear + residual + LayerNorm in one launch (bf16 mode, model width N = 384) -- replaces, inside a pre-norm block
  * (zoo/arch.py:94-97), the tail of one sub-block and the head of the next:
  *     x_out = residual + a W^T + bias          (proj :53 / fc2 :76 and the residual add :95 / :96; fp32 residual stream)
@@ -288,6 +277,22 @@ int dinox_cast_transpose_bf16(const float* src, void* dst, int R, int C, void* s
  * in src_base and dst_base), R, C, index of its first 32x32 tile}; total_tiles = sum of ceil(R/32)*ceil(C/32). */
 int dinox_cast_transpose_bf16_multi(const float* src_base, void* dst_base, const int64_t* table, int n_mats,
                                     int64_t total_tiles, void* stream);
+/* ------------------------------------------------------------------------------------------
+ * Glue between the big kernels, so that no framework elementwise kernel runs inside a training step.
+ *   take_rows: dst[dst_row0 + v][0..D) = src[v * src_stride + 0..D)   (fp32 -> dst_dtype).  With src = features + 0 and
+ *              src_stride = N*D this is `feats[:, 0]` (the CLS row handed to the DINO head, zoo/arch.py:260-261).
+ *   put_rows:  dst[v * dst_stride + 0..D) (+)= src[src_row0 + v][0..D)   (src_dtype -> fp32): the head's input gradient written
+ *              into row 0 of the feature gradient (the reference's slice backward: zero fill + copy + full-size add).
+ *   axpy:      y += alpha * x (fp32).     lincomb3: out[0] = a[0] + wb*b[0] + wc*c[0] (b, c may be NULL): the total loss
+ *              (scripts/phase5_big_run.py:1755-1766).     zero: asynchronous zero fill.
+ * ------------------------------------------------------------------------------------------ */
+int dinox_take_rows(const float* src, void* dst, int64_t V, int64_t src_stride, int D, int64_t dst_row0, int dst_dtype,
+                    void* stream);
+int dinox_put_rows(const void* src, float* dst, int64_t V, int64_t dst_stride, int D, int64_t src_row0, int src_dtype,
+                   int accumulate, void* stream);
+int dinox_axpy(float* y, const float* x, float alpha, int64_t n, void* stream);
+int dinox_lincomb3(const float* a, const float* b, const float* c, float wb, float wc, float* out, void* stream);
+int dinox_zero(void* p, int64_t bytes, void* stream);
 /* Elementwise helpers used by the host-side modules: y = gelu_erf(x) / dx = dy * gelu_erf'(x) (fp32). */
 int dinox_gelu_fwd(const float* x, float* y, int64_t n, void* stream);
 int dinox_gelu_bwd(const float* dy, const float* x, float* dx, int64_t n, void* stream);

@@ -50,7 +50,6 @@ if os.environ.get("VITB"):
     bqb, bdb, resb = rf(3 * Db), rf(Db), rf(M, Db)
     case("vitb qkv  NT K768 N2304 bias   ", lambda: ops.gemm(xb_, wqb, bias=bqb), 2 * M * Db * 3 * Db, M * Db * 2 + M * 3 * Db * 2)
     case("vitb proj NT K768 N768 bias+res", lambda: ops.gemm(xb_, wpb, bias=bdb, residual=resb, out_dtype=torch.float32), 2 * M * Db * Db, M * Db * 2 + 2 * M * Db * 4)
-case("mlpT  fused fc1+gelu+fc2+res     ", lambda: ops.mlp_fwd_fused(x, w1, bh, w2, bd, res), 4 * M * D * H, M * D * 2 + 2 * M * D * 4)
 if os.environ.get("SQUARE"):
     S = int(os.environ["SQUARE"])
     sa, sb = rb(S, S), rb(S, S)

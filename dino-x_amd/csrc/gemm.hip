@@ -37,6 +37,14 @@ static void to_params(const dinox_gemm_args* a, GemmParams& p) {
   p.alpha = a->alpha;
   p.bias = a->bias; p.residual = a->residual; p.ldr = a->ldr; p.aux = a->aux; p.ldaux = a->ldaux;
   p.colsum = a->colsum;
+  p.ws = a->ws;
+}
+
+extern "C" int64_t dinox_gemm_ws_bytes(const dinox_gemm_args* a) {
+  if (!a || a->M <= 0 || a->N <= 0 || a->K <= 0 || a->batch < 1) return 0;
+  GemmParams p;
+  to_params(a, p);
+  return p.in_dtype == DINOX_BF16 ? gemm_bf16_ws_bytes(p) : 0;
 }
 
 extern "C" const char* dinox_gemm_kernel_name(const dinox_gemm_args* a) {

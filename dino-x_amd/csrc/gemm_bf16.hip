@@ -17,6 +17,8 @@
 // A row-panel hit that XCD's private L2 (cdna_hip_programming.md T1, bijective form).
 #include <cstdlib>
 
+#include <cstring>
+
 #include "common.h"
 #include "gemm_common.h"
 
@@ -269,13 +271,21 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_bf16_tn(GemmParams p, int 
     __syncthreads();
   }
 
+  // Split-K results meet either in the caller's workspace -- partial tiles [split][M][N] and partial column sums
+  // [split * tiles_n + tn][M] by PLAIN stores, summed in split order by tn_reduce_kernel: bit-reproducible, and plain stores run at
+  // 6 TB/s where memory-side fp32 atomics run at 1.3 TB/s (33 MB per dW launch) -- or, without a workspace, through atomics.
+  const bool det = p.ws != nullptr && splits > 1;
   if (cs_wave && (lane & 31) == 0) {   // every column of csacc holds the same sums: lanes 0 and 32 own all 32 rows
+    float* csp = det ? (float*)p.ws + (int64_t)splits * p.M * p.N + ((int64_t)split * tiles_n + tn) * p.M : nullptr;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int64_t m = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-        if (m < p.M) atomicAdd(p.colsum + m, csacc[i][e]);
+        if (m < p.M) {
+          if (det) csp[m] = csacc[i][e];
+          else atomicAdd(p.colsum + m, csacc[i][e]);
+        }
       }
   }
 
@@ -290,7 +300,9 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_bf16_tn(GemmParams p, int 
       for (int e = 0; e < 16; ++e) {
         const int64_t m = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
         if (m >= p.M) continue;
-        if (splits > 1)
+        if (det)
+          ((float*)p.ws)[((int64_t)split * p.M + m) * p.N + n] = acc[i][j][e];              // alpha / ACCUM are applied by the reduction
+        else if (splits > 1)
           atomicAdd((float*)p.C + bz * p.strideC + m * p.ldc + n, acc[i][j][e] * p.alpha);  // C zeroed / accumulating
         else
           epilogue_store<OUT_DT>(p, bz, m, n, acc[i][j][e], bias);
@@ -401,13 +413,21 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_bf16_tn_dma(GemmParams p, 
     __syncthreads();
   }
 
+  // Split-K results meet either in the caller's workspace -- partial tiles [split][M][N] and partial column sums
+  // [split * tiles_n + tn][M] by PLAIN stores, summed in split order by tn_reduce_kernel: bit-reproducible, and plain stores run at
+  // 6 TB/s where memory-side fp32 atomics run at 1.3 TB/s (33 MB per dW launch) -- or, without a workspace, through atomics.
+  const bool det = p.ws != nullptr && splits > 1;
   if (cs_wave && (lane & 31) == 0) {   // every column of csacc holds the same sums: lanes 0 and 32 own all 32 rows
+    float* csp = det ? (float*)p.ws + (int64_t)splits * p.M * p.N + ((int64_t)split * tiles_n + tn) * p.M : nullptr;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int64_t m = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-        if (m < p.M) atomicAdd(p.colsum + m, csacc[i][e]);
+        if (m < p.M) {
+          if (det) csp[m] = csacc[i][e];
+          else atomicAdd(p.colsum + m, csacc[i][e]);
+        }
       }
   }
 
@@ -422,13 +442,62 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_bf16_tn_dma(GemmParams p, 
       for (int e = 0; e < 16; ++e) {
         const int64_t m = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
         if (m >= p.M) continue;
-        if (splits > 1)
+        if (det)
+          ((float*)p.ws)[((int64_t)split * p.M + m) * p.N + n] = acc[i][j][e];              // alpha / ACCUM are applied by the reduction
+        else if (splits > 1)
           atomicAdd((float*)p.C + bz * p.strideC + m * p.ldc + n, acc[i][j][e] * p.alpha);  // C zeroed / accumulating
         else
           epilogue_store<OUT_DT>(p, bz, m, n, acc[i][j][e], bias);
       }
     }
   }
+}
+
+// Second stage of the deterministic split-K reduction: C (+)= alpha * sum_s part[s] in split order (4 elements per thread), then
+// colsum (+)= sum_t cs_part[t] over the splits * tiles_n partial column sums, in order.
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ part, int splits, int64_t MN, float alpha, float* __restrict__ C,
+                                                       int accumulate, const float* __restrict__ cs_part, int cs_terms, int64_t M,
+                                                       float* __restrict__ colsum) {
+  const int64_t n4 = MN >> 2, tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nthreads = (int64_t)gridDim.x * 256;
+  for (int64_t i = tid; i < n4; i += nthreads) {
+    float4 a = reinterpret_cast<const float4*>(part)[i];
+    for (int s = 1; s < splits; ++s) {
+      const float4 b = reinterpret_cast<const float4*>(part + (int64_t)s * MN)[i];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    float4 c = accumulate ? reinterpret_cast<const float4*>(C)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    c.x += alpha * a.x; c.y += alpha * a.y; c.z += alpha * a.z; c.w += alpha * a.w;
+    reinterpret_cast<float4*>(C)[i] = c;
+  }
+  for (int64_t i = (n4 << 2) + tid; i < MN; i += nthreads) {              // MN % 4 tail
+    float a = part[i];
+    for (int s = 1; s < splits; ++s) a += part[(int64_t)s * MN + i];
+    C[i] = (accumulate ? C[i] : 0.f) + alpha * a;
+  }
+  if (colsum)
+    for (int64_t m = tid; m < M; m += nthreads) {
+      float a = cs_part[m];
+      for (int t = 1; t < cs_terms; ++t) a += cs_part[(int64_t)t * M + m];
+      colsum[m] = (accumulate ? colsum[m] : 0.f) + a;
+    }
+}
+
+// Split plan of the TN products: one resident round (2 workgroups per CU x 256 CUs = 512 slots; a grid of 513..1023 would run two
+// rounds), at least 4 K-steps per workgroup.  Shared by the launcher and dinox_gemm_ws_bytes.
+static void tn_split_plan(const GemmParams& p, int& splits, int64_t& kps) {
+  const int tiles_m = (int)ceil_div(p.M, GB_BM), tiles_n = (int)ceil_div(p.N, GB_BN);
+  const int64_t ntile = (int64_t)tiles_m * tiles_n;
+  splits = 1;
+  const bool plain = (p.epilogue & ~DINOX_EPI_ACCUM) == 0 && p.out_dtype == DINOX_F32;
+  if (plain) {
+    const int64_t slots = 512, have = ntile * p.batch;
+    splits = (int)(slots / have);
+    const int64_t max_splits = ceil_div(p.K, 4 * GB_BK);
+    if (splits > max_splits) splits = (int)max_splits;
+    if (splits < 1) splits = 1;
+  }
+  kps = ceil_div(ceil_div(p.K, splits), GB_BK) * GB_BK;
+  splits = (int)ceil_div(p.K, kps);
 }
 
 static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
@@ -459,6 +528,23 @@ const char* gemm_bf16_variant(const GemmParams& p) {
   return nullptr;
 }
 
+// The deterministic reduction needs one contiguous [M][N] fp32 result of one problem, written by the DMA form of the TN kernel.
+static bool tn_det_ok(const GemmParams& p, const char* variant, int splits) {
+  return variant && !strcmp(variant, "gemm_bf16_tn_dma") && splits > 1 && p.batch == 1 && p.ldc == p.N && p.out_dtype == DINOX_F32 &&
+         (p.epilogue & ~DINOX_EPI_ACCUM) == 0;
+}
+
+int64_t gemm_bf16_ws_bytes(const GemmParams& p) {
+  const char* v = gemm_bf16_variant(p);
+  if (!v || strncmp(v, "gemm_bf16_tn", 12)) return 0;
+  int splits;
+  int64_t kps;
+  tn_split_plan(p, splits, kps);
+  if (!tn_det_ok(p, v, splits)) return 0;
+  const int tiles_n = (int)ceil_div(p.N, GB_BN);
+  return ((int64_t)splits * p.M * p.N + (p.colsum ? (int64_t)splits * tiles_n * p.M : 0)) * (int64_t)sizeof(float);
+}
+
 int launch_gemm_bf16(const GemmParams& p, hipStream_t st) {
   const char* v = gemm_bf16_variant(p);
   if (!v) return DINOX_EUNSUPPORTED;
@@ -475,21 +561,16 @@ int launch_gemm_bf16(const GemmParams& p, hipStream_t st) {
       hipLaunchKernelGGL((gemm_bf16_nt<DINOX_BF16>), grid, dim3(GB_THREADS), lds, st, p, tiles_m, tiles_n);
     return check_launch("gemm_bf16_nt");
   }
-  // TN: split K so that the grid has ~2 workgroups per CU; split results meet through fp32 atomics.
-  int splits = 1;
-  const bool plain = (p.epilogue & ~DINOX_EPI_ACCUM) == 0 && p.out_dtype == DINOX_F32;
-  if (plain) {
-    // one resident round: 2 workgroups per CU x 256 CUs = 512 slots; a grid of 513..1023 would run two rounds
-    const int64_t slots = 512, have = ntile * p.batch;
-    splits = (int)(slots / have);
-    const int64_t max_splits = ceil_div(p.K, 4 * GB_BK);  // at least 4 K-steps per workgroup
-    if (splits > max_splits) splits = (int)max_splits;
-    if (splits < 1) splits = 1;
-  }
-  int64_t kps = ceil_div(ceil_div(p.K, splits), GB_BK) * GB_BK;
-  splits = (int)ceil_div(p.K, kps);
+  // TN: split K so that the grid has ~2 workgroups per CU; split results meet in the caller's workspace (deterministic two-stage
+  // reduction) or, without one, through fp32 atomics.
+  int splits;
+  int64_t kps;
+  tn_split_plan(p, splits, kps);
   if (p.batch > 65535) return DINOX_EUNSUPPORTED;
-  if (splits > 1 && !(p.epilogue & DINOX_EPI_ACCUM)) {
+  GemmParams q = p;
+  const bool det = q.ws != nullptr && tn_det_ok(p, v, splits);
+  if (!det) q.ws = nullptr;
+  if (!det && splits > 1 && !(p.epilogue & DINOX_EPI_ACCUM)) {
     // zero C (rows may be strided by ldc; batch by strideC): contiguous case only, else fall back to 1 split
     if (p.ldc == p.N && (p.batch == 1 || p.strideC == p.M * p.N)) {
       hipError_t e = hipMemsetAsync(p.C, 0, (size_t)p.batch * p.M * p.N * sizeof(float), st);
@@ -499,24 +580,36 @@ int launch_gemm_bf16(const GemmParams& p, hipStream_t st) {
       kps = ceil_div(p.K, GB_BK) * GB_BK;
     }
   }
-  if (p.colsum && !(p.epilogue & DINOX_EPI_ACCUM)) {     // with ACCUM the column sums are added to what colsum holds, like C
+  if (!det && p.colsum && !(p.epilogue & DINOX_EPI_ACCUM)) {     // with ACCUM the column sums are added to what colsum holds, like C
     hipError_t e = hipMemsetAsync(p.colsum, 0, (size_t)p.M * sizeof(float), st);
     if (e != hipSuccess) return fail((int)e, "gemm_bf16_tn: memset colsum: %s", hipGetErrorString(e));
   }
   if (ntile * splits > 0x7fffffff) return DINOX_EUNSUPPORTED;
   dim3 grid((unsigned)(ntile * splits), (unsigned)p.batch);
+  const char* what = "gemm_bf16_tn";
   if (v[12] == '_') {  // "gemm_bf16_tn_dma"
+    what = "gemm_bf16_tn_dma";
     if (p.out_dtype == DINOX_F32)
-      hipLaunchKernelGGL((gemm_bf16_tn_dma<DINOX_F32>), grid, dim3(GB_THREADS), lds, st, p, tiles_m, tiles_n, splits, kps);
+      hipLaunchKernelGGL((gemm_bf16_tn_dma<DINOX_F32>), grid, dim3(GB_THREADS), lds, st, q, tiles_m, tiles_n, splits, kps);
     else
-      hipLaunchKernelGGL((gemm_bf16_tn_dma<DINOX_BF16>), grid, dim3(GB_THREADS), lds, st, p, tiles_m, tiles_n, splits, kps);
-    return check_launch("gemm_bf16_tn_dma");
+      hipLaunchKernelGGL((gemm_bf16_tn_dma<DINOX_BF16>), grid, dim3(GB_THREADS), lds, st, q, tiles_m, tiles_n, splits, kps);
+  } else if (p.out_dtype == DINOX_F32) {
+    hipLaunchKernelGGL((gemm_bf16_tn<DINOX_F32>), grid, dim3(GB_THREADS), lds, st, q, tiles_m, tiles_n, splits, kps);
+  } else {
+    hipLaunchKernelGGL((gemm_bf16_tn<DINOX_BF16>), grid, dim3(GB_THREADS), lds, st, q, tiles_m, tiles_n, splits, kps);
   }
-  if (p.out_dtype == DINOX_F32)
-    hipLaunchKernelGGL((gemm_bf16_tn<DINOX_F32>), grid, dim3(GB_THREADS), lds, st, p, tiles_m, tiles_n, splits, kps);
-  else
-    hipLaunchKernelGGL((gemm_bf16_tn<DINOX_BF16>), grid, dim3(GB_THREADS), lds, st, p, tiles_m, tiles_n, splits, kps);
-  return check_launch("gemm_bf16_tn");
+  if (int rc = check_launch(what)) return rc;
+  if (det) {
+    const int64_t MN = p.M * p.N;
+    int64_t blocks = ceil_div(MN >> 2, (int64_t)256);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    const float* part = (const float*)p.ws;
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, part, splits, MN, p.alpha, (float*)p.C,
+                       (p.epilogue & DINOX_EPI_ACCUM) ? 1 : 0, part + (int64_t)splits * MN, splits * tiles_n, p.M, p.colsum);
+    return check_launch("gemm_bf16_tn_reduce");
+  }
+  return 0;
 }
 
 }  // namespace dinox

@@ -19,6 +19,7 @@ struct GemmParams {
   void* aux;
   int64_t ldaux;
   float* colsum;
+  void* ws;
 };
 
 // One output element: BIAS -> GELU(+aux write) -> DGELU(aux read) -> RESIDUAL -> ACCUM -> store.
@@ -44,5 +45,6 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int64_t bz, 
 int launch_gemm_f32(const GemmParams& p, hipStream_t st);
 const char* gemm_bf16_variant(const GemmParams& p);  // kernel the bf16 dispatcher would use, or nullptr
 int launch_gemm_bf16(const GemmParams& p, hipStream_t st);  // returns DINOX_EUNSUPPORTED when it cannot take the shape
+int64_t gemm_bf16_ws_bytes(const GemmParams& p);            // workspace of the deterministic split-K reduction (0: none)
 
 }  // namespace dinox

@@ -226,21 +226,27 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_generic(const void* __restr
   for (int c = threadIdx.x; c < 2 * dim; c += LN_THREADS) out[c] = lds[c];
 }
 
-// Stage 2: out[c] = sum_p ws[p][c].  grid (2*dim/64, 16): thread (c, g) sums parts p == 4*blockIdx.y + g (mod 64),
-// the 4 groups meet in LDS and the 16 grid rows through fp32 atomics on the zeroed outputs.
+// Stage 2: out[c] (+)= sum_p ws[p][c], in a FIXED order (no atomics: bit-reproducible).  A block owns 16 columns: thread (c, g),
+// g < 16, sums the parts p == g (mod 16) in increasing p, the 16 groups meet in LDS as a fixed tree, the result is stored (or added
+// to what the gradient arena holds) by one thread per column.
 __global__ __launch_bounds__(256) void ln_bwd_reduce(const float* __restrict__ ws, float* __restrict__ dw, float* __restrict__ db,
-                                                     int parts, int dim) {
-  __shared__ float red[4][64];
-  const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
+                                                     int parts, int dim, int accumulate) {
+  __shared__ float red[16][17];
+  const int cl = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   float s = 0.f;
   if (c < 2 * dim)
-    for (int p = blockIdx.y * 4 + g; p < parts; p += 64) s += ws[(size_t)p * 2 * dim + c];
+    for (int p = g; p < parts; p += 16) s += ws[(size_t)p * 2 * dim + c];
   red[g][cl] = s;
   __syncthreads();
   if (g == 0 && c < 2 * dim) {
-    const float t = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
-    atomicAdd(c < dim ? &dw[c] : &db[c - dim], t);
+    float t[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t[k] = red[k][cl];
+    const float v = (((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]))) +
+                    (((t[8] + t[9]) + (t[10] + t[11])) + ((t[12] + t[13]) + (t[14] + t[15])));
+    float* dst = c < dim ? &dw[c] : &db[c - dim];
+    *dst = (accumulate ? *dst : 0.f) + v;
   }
 }
 
@@ -315,11 +321,6 @@ extern "C" int dinox_layernorm_bwd(const void* dy, const float* x, const float* 
 #undef LN_BWD
   int rc = check_launch("layernorm_bwd");
   if (rc) return rc;
-  if (!accumulate) {                       // the reduce kernel adds its partial sums with atomics
-    hipError_t me = hipMemsetAsync(dw, 0, (size_t)dim * sizeof(float), st);
-    if (me == hipSuccess) me = hipMemsetAsync(db, 0, (size_t)dim * sizeof(float), st);
-    if (me != hipSuccess) return fail((int)me, "layernorm_bwd: memset: %s", hipGetErrorString(me));
-  }
-  hipLaunchKernelGGL(ln_bwd_reduce, dim3((unsigned)ceil_div(2 * dim, 64), 16), dim3(256), 0, st, wsf, dw, db, parts, dim);
+  hipLaunchKernelGGL(ln_bwd_reduce, dim3((unsigned)ceil_div(2 * dim, 16)), dim3(256), 0, st, wsf, dw, db, parts, dim, accumulate ? 1 : 0);
   return check_launch("layernorm_bwd_reduce");
 }

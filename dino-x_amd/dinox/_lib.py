@@ -31,7 +31,7 @@ class GemmArgs(C.Structure):
         ("batch", i64), ("strideA", i64), ("strideB", i64), ("strideC", i64),
         ("transA", i32), ("transB", i32), ("in_dtype", i32), ("out_dtype", i32), ("epilogue", i32),
         ("alpha", f32),
-        ("bias", vp), ("residual", vp), ("ldr", i64), ("aux", vp), ("ldaux", i64), ("colsum", vp),
+        ("bias", vp), ("residual", vp), ("ldr", i64), ("aux", vp), ("ldaux", i64), ("colsum", vp), ("ws", vp),
     ]
 
 
@@ -42,6 +42,7 @@ SIGNATURES = {
     "dinox_device_ok": (i32, []),
     "dinox_gemm": (i32, [C.POINTER(GemmArgs), vp]),
     "dinox_gemm_kernel_name": (C.c_char_p, [C.POINTER(GemmArgs)]),
+    "dinox_gemm_ws_bytes": (i64, [C.POINTER(GemmArgs)]),
     "dinox_colsum": (i32, [vp, vp, i64, i64, i64, i32, i32, vp]),
     "dinox_linear_residual_ln_ok": (i32, [i64, i32, i32]),
     "dinox_linear_residual_ln": (i32, [vp, vp, vp, vp, vp, vp, vp, f32, vp, i32, vp, vp, i64, i32, i32, vp]),

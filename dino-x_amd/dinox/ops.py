@@ -187,7 +187,11 @@ def gemm(A: Tensor, B: Tensor, *, transA=False, transB=False, out: Optional[Tens
         A=_p(A), B=_p(B), C=_p(out), M=M, N=N, K=K, lda=a2[1], ldb=b2[1], ldc=N, batch=batch,
         strideA=a2[0] * a2[1] if batched else 0, strideB=(b2[0] * b2[1] if (batched and B.dim() == 3) else 0),
         strideC=M * N, transA=int(transA), transB=int(transB), in_dtype=_code(A.dtype), out_dtype=_code(odt),
-        epilogue=epi, alpha=alpha, bias=_p(bias), residual=_p(residual), ldr=N, aux=_p(aux), ldaux=N, colsum=_p(colsum_out))
+        epilogue=epi, alpha=alpha, bias=_p(bias), residual=_p(residual), ldr=N, aux=_p(aux), ldaux=N, colsum=_p(colsum_out), ws=None)
+    if transA and transB and not batched and A.dtype == torch.bfloat16 and not _TN_ATOMICS:
+        need = lib.dinox_gemm_ws_bytes(C.byref(g))       # split-K dW product: deterministic two-stage reduction through a workspace
+        if need:
+            g.ws = _p(_tn_workspace(need, A.device))
     if TRACE_KERNELS is not None:
         TRACE_KERNELS.append(lib.dinox_gemm_kernel_name(C.byref(g)).decode())
     if GEMM_TIMER is not None:
@@ -195,6 +199,19 @@ def gemm(A: Tensor, B: Tensor, *, transA=False, transB=False, out: Optional[Tens
     else:
         check(lib.dinox_gemm(C.byref(g), _stream()), "dinox_gemm")
     return out
+
+
+_TN_ATOMICS = bool(os.environ.get("DINOX_TN_ATOMICS"))      # A/B: split-K dW products through fp32 atomics (round-1 behaviour, not reproducible)
+_TN_WS: dict = {}
+
+
+def _tn_workspace(nbytes: int, device) -> Tensor:
+    """One growable scratch buffer per (device, stream): consecutive split-K products of a stream reuse it in stream order."""
+    key = (device, _stream())
+    ws = _TN_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _TN_WS[key] = torch.empty(max(nbytes, 40 << 20), dtype=torch.uint8, device=device)
+    return ws
 
 
 def colsum(x: Tensor, out: Optional[Tensor] = None, accumulate=False) -> Tensor:

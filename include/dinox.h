@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DINOX_ABI_VERSION 1
+#define DINOX_ABI_VERSION 2
 
 /* dtype codes */
 #define DINOX_F32 0
@@ -94,9 +94,18 @@ typedef struct dinox_gemm_args {
   float* colsum;                       /* optional, transA = 1 only: colsum[m] = sum_k A(m,k) (overwritten; added to
                                         * under ACCUM, like C) -- the bias
                                         * gradient sum_rows(dY) rides along the dW = dY^T X product that already streams dY */
+  void* ws;                            /* optional workspace of dinox_gemm_ws_bytes() bytes, ZERO when first handed over (the library
+                                        * leaves it zero).  With it a split-K product (the dW = dY^T X products, K = every token of
+                                        * the batch) meets in a fixed-order two-stage reduction -- partial tiles by plain stores, the
+                                        * last workgroup of a tile sums them in split order -- instead of fp32 atomics: results are
+                                        * bit-reproducible from run to run, and 33 MB of memory-side atomics per launch (1.3 TB/s on
+                                        * this part) become plain stores (6 TB/s).  NULL: atomics as before.  One launch at a time
+                                        * per workspace (stream-ordered reuse is fine). */
 } dinox_gemm_args;
 
 int dinox_gemm(const dinox_gemm_args* args, void* stream);
+/* Bytes of workspace that make this product deterministic (0: it needs none / cannot use one). */
+int64_t dinox_gemm_ws_bytes(const dinox_gemm_args* args);
 /* Name of the device kernel dinox_gemm would launch for these arguments ("gemm_bf16_nt", "gemm_bf16_tn",
  * "gemm_f32"); host-only query used by bench.py to attribute per-launch timings.  Static string. */
 const char* dinox_gemm_kernel_name(const dinox_gemm_args* args);

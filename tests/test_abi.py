@@ -46,7 +46,7 @@ def test_ctypes_table_matches_header():
 
 def test_version_and_error_plumbing():
     from dinox import _lib
-    assert _lib.lib.dinox_version() == 1
+    assert _lib.lib.dinox_version() == 2
     # argument validation happens on the host before any launch: safe without a GPU
     rc = _lib.lib.dinox_layernorm_fwd(None, None, None, None, None, None, 4, 8, 1e-5, 0, None)
     assert rc == -1 and "null pointer" in _lib.last_error()

@@ -1466,3 +1466,66 @@ def test_graph_replay_matches_eager(dx):
         close(cg, ce, tol, 1e-6, "centre")
         close(tg, te, 10 * tol, 1e-4, "teacher arena")
         assert float(((pg - pe).abs() <= 10 * tol * pe.abs() + 2.1e-3).double().mean()) == 1.0
+
+
+@pytest.mark.parametrize("K,M,N,cs", [(102912, 1536, 384, True), (25728, 384, 384, True), (5000, 1152, 384, False), (804 * 32 + 17, 136, 264, True)])
+def test_gemm_tn_split_k_is_bit_reproducible(dx, K, M, N, cs):
+    """The dW products (C[M,N] = A[K,M]^T B[K,N], K = every token of the batch) split K over the chip.  With the workspace the host
+    side hands them (ops._tn_workspace) the splits meet in a fixed-order two-stage reduction instead of fp32 atomics: five launches
+    give bit-identical results -- also when accumulating into a gradient that is already there, and for the bias gradient riding
+    along -- and equal fp64 on the same bf16 operands."""
+    ops, _ = dx
+    g = torch.Generator().manual_seed(K + M)
+    A = (torch.randn(K, M, generator=g) * 0.5).bfloat16().to(DEV)
+    B = (torch.randn(K, N, generator=g) * 0.5).bfloat16().to(DEV)
+    C0 = torch.randn(M, N, generator=g).to(DEV)
+    c0 = torch.randn(M, generator=g).to(DEV)
+    outs = []
+    ops.TRACE_KERNELS = []
+    try:
+        for _ in range(5):
+            C, cvec = C0.clone(), c0.clone()
+            ops.gemm(A, B, transA=True, transB=True, out=C, accumulate=True, colsum_out=cvec if cs else None)
+            P = ops.gemm(A, B, transA=True, transB=True, out_dtype=torch.float32)
+            outs.append((C, cvec, P))
+        assert set(ops.TRACE_KERNELS) == {"gemm_bf16_tn_dma"}
+    finally:
+        ops.TRACE_KERNELS = None
+    for C, cvec, P in outs[1:]:
+        assert torch.equal(C, outs[0][0]) and torch.equal(cvec, outs[0][1]) and torch.equal(P, outs[0][2])
+    ref = A.double().t() @ B.double()
+    assert rel_l2(outs[0][2], ref) < 2e-6
+    assert rel_l2(outs[0][0] - C0, ref) < 1e-5
+    if cs:
+        assert rel_l2(outs[0][1] - c0, A.double().sum(0)) < 1e-5
+
+
+def test_training_steps_are_bit_reproducible(dx):
+    """Two runs of three bf16 optimiser steps from the same state end in bit-identical student, teacher, Adam moments and centre:
+    no kernel of the step leaves the order of a floating-point sum to the scheduler (round 1: the split-K atomics of the dW products did)."""
+    ops, arch = dx
+    from dinox.engine import StepHyperParams, TrainEngine
+    kw = dict(img_size=64, patch=16, dim=384, depth=2, heads=6, num_registers=4, scale_aware=True)
+    torch.manual_seed(3)
+    ref = arch.DinoStudentTeacher(arch.PatchViT(**kw), 1024)
+    torch.nn.init.xavier_uniform_(ref.backbone.scale_embed.mlp[2].weight)
+    sd = {k: v.clone() for k, v in ref.state_dict().items()}
+    g = torch.Generator().manual_seed(4)
+    batches = [(torch.randn(64, 3, 64, 64, generator=g).to(DEV), (torch.rand(32, 3, generator=g) + 0.5).repeat(2, 1).to(DEV)) for _ in range(3)]
+
+    def run():
+        student = arch.DinoStudentTeacher(arch.PatchViT(**kw), 1024)
+        teacher = arch.DinoStudentTeacher(arch.PatchViT(**kw), 1024)
+        student.load_state_dict(sd)
+        teacher.load_state_dict(sd)
+        eng = TrainEngine(student.to(DEV), teacher.to(DEV), 1024, StepHyperParams(lr=1e-3, warmup_steps=2, max_steps=8, ema=0.9, koleo_weight=0.1),
+                          amp_dtype=torch.bfloat16)
+        for b, s in batches:
+            eng.step(b, s)
+        return [t.clone() for t in (eng.flat_p, eng.flat_t, eng.adam_m, eng.adam_v, eng.center, eng.flat_g)], eng.scalars()["loss"]
+
+    a, la = run()
+    b, lb = run()
+    assert la == lb
+    for name, x, y in zip(("student", "teacher", "adam_m", "adam_v", "centre", "last gradient"), a, b):
+        assert torch.equal(x, y), f"{name}: {int((x != y).sum())} of {x.numel()} elements differ between two identical runs"

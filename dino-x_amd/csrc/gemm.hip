@@ -4,23 +4,37 @@
 
 namespace dinox {
 
-// out[n] (+)= sum_m x[m][n].  Block = 256 threads = 64 columns x 4 row-groups; grid.x tiles N by 64,
-// grid.y splits M; partial sums meet through fp32 atomics on a pre-zeroed (or accumulating) output.
+// out[n] (+)= sum_m x[m][n] in a FIXED order (no atomics: bit-reproducible).  Block = 1024 threads = 64 columns x 16 row-groups; a
+// block owns 64 columns and all M rows: thread (c, g) sums rows g, g + 16, ... (four independent partial sums in flight), the 16
+// groups meet in LDS as a fixed tree.  Only the fp32 parity mode and bias-only backward passes come here (the bf16 dW products
+// produce their bias gradient themselves), so a grid of N / 64 workgroups is enough.
 template <int DT>
-__global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ x, float* __restrict__ out, int64_t M,
-                                                     int64_t N, int64_t ldx, int64_t rows_per_block) {
-  __shared__ float red[4][64];
+__global__ __launch_bounds__(1024) void colsum_kernel(const void* __restrict__ x, float* __restrict__ out, int64_t M,
+                                                      int64_t N, int64_t ldx, int accumulate) {
+  __shared__ float red[16][64];
   const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int64_t n = (int64_t)blockIdx.x * 64 + c;
-  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
-  int64_t r1 = r0 + rows_per_block;
-  if (r1 > M) r1 = M;
-  float s = 0.f;
-  if (n < N)
-    for (int64_t r = r0 + g; r < r1; r += 4) s += elem<DT>::ld(x, r * ldx + n);
-  red[g][c] = s;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (n < N) {
+    int64_t r = g;
+    for (; r + 48 < M; r += 64) {
+      s0 += elem<DT>::ld(x, r * ldx + n);
+      s1 += elem<DT>::ld(x, (r + 16) * ldx + n);
+      s2 += elem<DT>::ld(x, (r + 32) * ldx + n);
+      s3 += elem<DT>::ld(x, (r + 48) * ldx + n);
+    }
+    for (; r < M; r += 16) s0 += elem<DT>::ld(x, r * ldx + n);
+  }
+  red[g][c] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (g == 0 && n < N) atomicAdd(&out[n], (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
+  if (g == 0 && n < N) {
+    float t[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t[k] = red[k][c];
+    const float v = (((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]))) +
+                    (((t[8] + t[9]) + (t[10] + t[11])) + ((t[12] + t[13]) + (t[14] + t[15])));
+    out[n] = (accumulate ? out[n] : 0.f) + v;
+  }
 }
 
 }  // namespace dinox
@@ -93,20 +107,10 @@ extern "C" int dinox_colsum(const void* x, float* out, int64_t M, int64_t N, int
   DX_REQUIRE(M > 0 && N > 0 && ldx >= N, DINOX_EINVAL, "colsum: M=%lld N=%lld ldx=%lld", (long long)M, (long long)N, (long long)ldx);
   DX_REQUIRE(dtype == DINOX_F32 || dtype == DINOX_BF16, DINOX_EINVAL, "colsum: dtype %d", dtype);
   hipStream_t st = as_stream(stream);
-  if (!accumulate) {
-    hipError_t e = hipMemsetAsync(out, 0, (size_t)N * sizeof(float), st);
-    if (e != hipSuccess) return fail((int)e, "colsum: memset: %s", hipGetErrorString(e));
-  }
-  const int64_t nb = ceil_div(N, 64);
-  int64_t splits = ceil_div(2048, nb);                 // aim for ~2048 blocks
-  const int64_t max_splits = ceil_div(M, 64);
-  if (splits > max_splits) splits = max_splits;
-  if (splits < 1) splits = 1;
-  const int64_t rpb = ceil_div(M, splits);
-  dim3 grid((unsigned)nb, (unsigned)ceil_div(M, rpb));
+  dim3 grid((unsigned)ceil_div(N, 64));
   if (dtype == DINOX_F32)
-    hipLaunchKernelGGL((colsum_kernel<DINOX_F32>), grid, dim3(256), 0, st, x, out, M, N, ldx, rpb);
+    hipLaunchKernelGGL((colsum_kernel<DINOX_F32>), grid, dim3(1024), 0, st, x, out, M, N, ldx, accumulate ? 1 : 0);
   else
-    hipLaunchKernelGGL((colsum_kernel<DINOX_BF16>), grid, dim3(256), 0, st, x, out, M, N, ldx, rpb);
+    hipLaunchKernelGGL((colsum_kernel<DINOX_BF16>), grid, dim3(1024), 0, st, x, out, M, N, ldx, accumulate ? 1 : 0);
   return check_launch("colsum");
 }

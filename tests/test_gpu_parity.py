@@ -996,12 +996,10 @@ def test_rccl_call_surface_world1(tmp_path):
         assert r.returncode == 0, r.stdout.decode(errors="replace")[-2000:]
         outs[tag] = torch.load(out)
     a, b = outs["plain"], outs["rccl"]
-    # not bit for bit: the split-K dW products meet in fp32 atomics, whose order differs from run to run (and Adam turns a
-    # numerically-zero gradient into a +-lr move); two plain runs differ by as much
-    assert a["loss"] == pytest.approx(b["loss"], rel=2e-4) and a["grad_norm"] == pytest.approx(b["grad_norm"], rel=2e-4)
-    assert torch.allclose(a["center"], b["center"], rtol=1e-5, atol=1e-7)
-    d = (a["flat_p"] - b["flat_p"]).abs()
-    assert float((d <= 1e-5).double().mean()) > 0.99 and float(d.max()) <= 2.1e-3
+    # bit for bit: a sum over one rank is the identity and (since round 2) no kernel of the step leaves a summation order to the
+    # scheduler -- round 1 had to allow 2e-4 here because the split-K dW products met in fp32 atomics
+    assert a["loss"] == b["loss"] and a["grad_norm"] == b["grad_norm"]
+    assert torch.equal(a["center"], b["center"]) and torch.equal(a["flat_p"], b["flat_p"])
 
 
 @pytest.mark.parametrize("name", ["configs0_vit_tiny_cifar", "configs1_vit_small_not_scale_aware"])

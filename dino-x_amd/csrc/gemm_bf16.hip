@@ -313,9 +313,16 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_bf16_tn(GemmParams p, int 
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 
-template <int OUT_DT>
-__global__ __launch_bounds__(GB_THREADS, 2) void gemm_bf16_tn_dma(GemmParams p, int tiles_m, int tiles_n, int splits,
-                                                              int64_t k_per_split) {
+// PF > 0: a FIFTH wave runs PF K-steps ahead of the four computing waves and touches every 64-byte sector of the slabs they will
+// stage (one dword per sector, LDS-DMA into a scratch corner: no VGPR is written, nothing waits for it).  Why: the staging
+// queue of a wave retires in order and a K-step ends at a barrier, so ONE sector that has to come from HBM holds the whole
+// 32 KB step for an HBM round trip (~1.5-2 us under load) although four fifths of its bytes are L2 hits -- the LDS pipeline then
+// runs at bytes-in-flight / HBM latency (64 KB per CU / 1.4 us = 12 TB/s over the chip: the "40-50 GB/s per CU whatever the kernel
+// does" of round 1) instead of L2 speed.  The prefetcher has its own queue: it pays the HBM latency PF steps early, the computing
+// waves find their sectors in L2.
+template <int OUT_DT, int PF>
+__global__ __launch_bounds__(GB_THREADS + (PF ? 64 : 0), 2) void gemm_bf16_tn_dma(GemmParams p, int tiles_m, int tiles_n, int splits,
+                                                                             int64_t k_per_split, int pf_dist) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int wr = wv >> 1, wc = wv & 1;
@@ -386,6 +393,31 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_bf16_tn_dma(GemmParams p, 
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)(sb + q * 1024), 16, voffB[q] + kt * stepB, 0, 0, 0);
     }
   };
+  if (PF && wvu == 4) {
+    // lane -> (row = lane >> 2 of 16, sector = lane & 3 of the 256-byte row piece); four instructions cover the 64 rows of a slab
+    char* const dump = smem + 4 * GB_TILE_BYTES;
+    const int r = lane >> 2, sec = lane & 3;
+    int64_t ma = m0 + sec * 32, nb = n0 + sec * 32;
+    ma = ma < p.M ? ma : p.M - 8;
+    nb = nb < p.N ? nb : p.N - 8;
+    const unsigned pa = (unsigned)(((kbeg + r) * p.lda + ma) * 2), pb = (unsigned)(((kbeg + r) * p.ldb + nb) * 2);
+    const unsigned rowsA = (unsigned)(16 * p.lda * 2), rowsB = (unsigned)(16 * p.ldb * 2);
+    auto touch = [&](int kt) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)dump, 4, pa + kt * stepA + q * rowsA, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)dump, 4, pb + kt * stepB + q * rowsB, 0, 0, 0);
+      }
+    };
+    for (int kt = 1; kt <= pf_dist && kt < nk; ++kt) touch(kt);
+    __builtin_amdgcn_s_barrier();
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 + pf_dist < nk) touch(kt + 1 + pf_dist);
+      __builtin_amdgcn_s_barrier();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
   if (nk > 0) stage(0, 0);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
@@ -453,33 +485,75 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_bf16_tn_dma(GemmParams p, 
   }
 }
 
-// Second stage of the deterministic split-K reduction: C (+)= alpha * sum_s part[s] in split order (4 elements per thread), then
-// colsum (+)= sum_t cs_part[t] over the splits * tiles_n partial column sums, in order.
+// Second stage of the deterministic split-K reduction: C (+)= alpha * sum_s part[s], colsum (+)= sum_t cs_part[t], always in the same
+// order.  A block of 256 threads owns 64 float4 (or 64 column sums): four groups of 64 threads each take a quarter of the splits in
+// increasing order -- their loads in flight together, eight per round -- and meet in LDS as ((g0 + g1) + (g2 + g3)).  (A first
+// version walked all splits per thread: 14-85 dependent round trips, 44 us per launch for 50 MB.)
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ part, int splits, int64_t MN, float alpha, float* __restrict__ C,
                                                        int accumulate, const float* __restrict__ cs_part, int cs_terms, int64_t M,
-                                                       float* __restrict__ colsum) {
-  const int64_t n4 = MN >> 2, tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nthreads = (int64_t)gridDim.x * 256;
-  for (int64_t i = tid; i < n4; i += nthreads) {
-    float4 a = reinterpret_cast<const float4*>(part)[i];
-    for (int s = 1; s < splits; ++s) {
-      const float4 b = reinterpret_cast<const float4*>(part + (int64_t)s * MN)[i];
-      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+                                                       float* __restrict__ colsum, int c_blocks) {
+  __shared__ float4 red[4][64];
+  const int l = threadIdx.x & 63, g = threadIdx.x >> 6;
+  if ((int)blockIdx.x < c_blocks) {
+    const int64_t n4 = MN >> 2, i = (int64_t)blockIdx.x * 64 + l;
+    const int per = (splits + 3) >> 2, s_lo = g * per, s_hi = s_lo + per < splits ? s_lo + per : splits;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n4) {
+      for (int s0 = s_lo; s0 < s_hi; s0 += 8) {
+        float4 b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          b[u] = s0 + u < s_hi ? reinterpret_cast<const float4*>(part + (int64_t)(s0 + u) * MN)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          a.x += b[u].x; a.y += b[u].y; a.z += b[u].z; a.w += b[u].w;
+        }
+      }
     }
-    float4 c = accumulate ? reinterpret_cast<const float4*>(C)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    c.x += alpha * a.x; c.y += alpha * a.y; c.z += alpha * a.z; c.w += alpha * a.w;
-    reinterpret_cast<float4*>(C)[i] = c;
-  }
-  for (int64_t i = (n4 << 2) + tid; i < MN; i += nthreads) {              // MN % 4 tail
-    float a = part[i];
-    for (int s = 1; s < splits; ++s) a += part[(int64_t)s * MN + i];
-    C[i] = (accumulate ? C[i] : 0.f) + alpha * a;
-  }
-  if (colsum)
-    for (int64_t m = tid; m < M; m += nthreads) {
-      float a = cs_part[m];
-      for (int t = 1; t < cs_terms; ++t) a += cs_part[(int64_t)t * M + m];
-      colsum[m] = (accumulate ? colsum[m] : 0.f) + a;
+    red[g][l] = a;
+    __syncthreads();
+    if (g == 0 && i < n4) {
+      const float4 r0 = red[0][l], r1 = red[1][l], r2 = red[2][l], r3 = red[3][l];
+      float4 c = accumulate ? reinterpret_cast<const float4*>(C)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      c.x += alpha * ((r0.x + r1.x) + (r2.x + r3.x));
+      c.y += alpha * ((r0.y + r1.y) + (r2.y + r3.y));
+      c.z += alpha * ((r0.z + r1.z) + (r2.z + r3.z));
+      c.w += alpha * ((r0.w + r1.w) + (r2.w + r3.w));
+      reinterpret_cast<float4*>(C)[i] = c;
     }
+    if (blockIdx.x == 0 && threadIdx.x < (MN & 3)) {                      // MN % 4 tail (never on this path: M, N are multiples of 8)
+      const int64_t j = (n4 << 2) + threadIdx.x;
+      float t = 0.f;
+      for (int s2 = 0; s2 < splits; ++s2) t += part[(int64_t)s2 * MN + j];
+      C[j] = (accumulate ? C[j] : 0.f) + alpha * t;
+    }
+  } else {                                                                 // column sums: 64 of them per block
+    const int64_t m = (int64_t)((int)blockIdx.x - c_blocks) * 64 + l;
+    const int per = (cs_terms + 3) >> 2, t_lo = g * per, t_hi = t_lo + per < cs_terms ? t_lo + per : cs_terms;
+    float a = 0.f;
+    if (m < M) {
+      for (int t0 = t_lo; t0 < t_hi; t0 += 8) {
+        float b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) b[u] = t0 + u < t_hi ? cs_part[(int64_t)(t0 + u) * M + m] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a += b[u];
+      }
+    }
+    red[g][l].x = a;
+    __syncthreads();
+    if (g == 0 && m < M) colsum[m] = (accumulate ? colsum[m] : 0.f) + ((red[0][l].x + red[1][l].x) + (red[2][l].x + red[3][l].x));
+  }
+}
+
+static int launch_tn_reduce(const GemmParams& p, int splits, int tiles_n, hipStream_t st) {
+  const int64_t MN = p.M * p.N;
+  const int c_blocks = (int)ceil_div(MN >> 2, (int64_t)64);
+  const int cs_blocks = p.colsum ? (int)ceil_div(p.M, (int64_t)64) : 0;
+  const float* part = (const float*)p.ws;
+  hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)(c_blocks + cs_blocks)), dim3(256), 0, st, part, splits, MN, p.alpha, (float*)p.C,
+                     (p.epilogue & DINOX_EPI_ACCUM) ? 1 : 0, part + (int64_t)splits * MN, splits * tiles_n, p.M, p.colsum, c_blocks);
+  return check_launch("gemm_bf16_tn_reduce");
 }
 
 // Split plan of the TN products: one resident round (2 workgroups per CU x 256 CUs = 512 slots; a grid of 513..1023 would run two
@@ -501,6 +575,9 @@ static void tn_split_plan(const GemmParams& p, int& splits, int64_t& kps) {
 }
 
 static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+int tn_big_plan(const GemmParams& p, int& tiles_m, int& tiles_n, int& splits, int64_t& kps);     // gemm_bf16_tnbig.hip
+int64_t tn_big_ws_bytes(const GemmParams& p);
+int launch_gemm_bf16_tn_big(const GemmParams& p, hipStream_t st, int& splits_out, int& tiles_n_out);
 bool gemm_bf16_nt_glds_ok(const GemmParams& p);
 int launch_gemm_bf16_nt_glds(const GemmParams& p, hipStream_t st);
 bool gemm_bf16_nt_areg_ok(const GemmParams& p);
@@ -522,6 +599,11 @@ const char* gemm_bf16_variant(const GemmParams& p) {
   }
   if (p.transA == 0 && p.transB == 0 && (p.K & 7) == 0) return "gemm_bf16_nt";
   if (p.transA == 1 && p.transB == 1 && (p.M & 7) == 0 && (p.N & 7) == 0) {
+    if (p.ws) {                                     // with a workspace the long-K dW products run on big tiles (gemm_bf16_tnbig.hip)
+      int a, b, c;
+      int64_t d;
+      if (tn_big_plan(p, a, b, c, d)) return "gemm_bf16_tn_big";
+    }
     const bool small = p.K * p.lda * 2 < (int64_t)0x7fffffff && p.K * p.ldb * 2 < (int64_t)0x7fffffff && p.M >= 8 && p.N >= 8;
     return small ? "gemm_bf16_tn_dma" : "gemm_bf16_tn";
   }
@@ -535,6 +617,7 @@ static bool tn_det_ok(const GemmParams& p, const char* variant, int splits) {
 }
 
 int64_t gemm_bf16_ws_bytes(const GemmParams& p) {
+  if (const int64_t big = tn_big_ws_bytes(p)) return big;
   const char* v = gemm_bf16_variant(p);
   if (!v || strncmp(v, "gemm_bf16_tn", 12)) return 0;
   int splits;
@@ -560,6 +643,11 @@ int launch_gemm_bf16(const GemmParams& p, hipStream_t st) {
     else
       hipLaunchKernelGGL((gemm_bf16_nt<DINOX_BF16>), grid, dim3(GB_THREADS), lds, st, p, tiles_m, tiles_n);
     return check_launch("gemm_bf16_nt");
+  }
+  if (!strcmp(v, "gemm_bf16_tn_big")) {
+    int sp = 1, tn_ = 1;
+    if (int rc = launch_gemm_bf16_tn_big(p, st, sp, tn_)) return rc;
+    return launch_tn_reduce(p, sp, tn_, st);
   }
   // TN: split K so that the grid has ~2 workgroups per CU; split results meet in the caller's workspace (deterministic two-stage
   // reduction) or, without one, through fp32 atomics.
@@ -589,26 +677,20 @@ int launch_gemm_bf16(const GemmParams& p, hipStream_t st) {
   const char* what = "gemm_bf16_tn";
   if (v[12] == '_') {  // "gemm_bf16_tn_dma"
     what = "gemm_bf16_tn_dma";
-    if (p.out_dtype == DINOX_F32)
-      hipLaunchKernelGGL((gemm_bf16_tn_dma<DINOX_F32>), grid, dim3(GB_THREADS), lds, st, q, tiles_m, tiles_n, splits, kps);
+    static const int pf = getenv("DINOX_TN_PREFETCH") ? atoi(getenv("DINOX_TN_PREFETCH")) : 0;      // K-steps of run-ahead (0: off)
+    if (pf > 0 && p.out_dtype == DINOX_F32)
+      hipLaunchKernelGGL((gemm_bf16_tn_dma<DINOX_F32, 1>), grid, dim3(GB_THREADS + 64), lds + 1024, st, q, tiles_m, tiles_n, splits, kps, pf);
+    else if (p.out_dtype == DINOX_F32)
+      hipLaunchKernelGGL((gemm_bf16_tn_dma<DINOX_F32, 0>), grid, dim3(GB_THREADS), lds, st, q, tiles_m, tiles_n, splits, kps, 0);
     else
-      hipLaunchKernelGGL((gemm_bf16_tn_dma<DINOX_BF16>), grid, dim3(GB_THREADS), lds, st, q, tiles_m, tiles_n, splits, kps);
+      hipLaunchKernelGGL((gemm_bf16_tn_dma<DINOX_BF16, 0>), grid, dim3(GB_THREADS), lds, st, q, tiles_m, tiles_n, splits, kps, 0);
   } else if (p.out_dtype == DINOX_F32) {
     hipLaunchKernelGGL((gemm_bf16_tn<DINOX_F32>), grid, dim3(GB_THREADS), lds, st, q, tiles_m, tiles_n, splits, kps);
   } else {
     hipLaunchKernelGGL((gemm_bf16_tn<DINOX_BF16>), grid, dim3(GB_THREADS), lds, st, q, tiles_m, tiles_n, splits, kps);
   }
   if (int rc = check_launch(what)) return rc;
-  if (det) {
-    const int64_t MN = p.M * p.N;
-    int64_t blocks = ceil_div(MN >> 2, (int64_t)256);
-    if (blocks > 4096) blocks = 4096;
-    if (blocks < 1) blocks = 1;
-    const float* part = (const float*)p.ws;
-    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, part, splits, MN, p.alpha, (float*)p.C,
-                       (p.epilogue & DINOX_EPI_ACCUM) ? 1 : 0, part + (int64_t)splits * MN, splits * tiles_n, p.M, p.colsum);
-    return check_launch("gemm_bf16_tn_reduce");
-  }
+  if (det) return launch_tn_reduce(p, splits, tiles_n, st);
   return 0;
 }
 

@@ -226,25 +226,23 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_generic(const void* __restr
   for (int c = threadIdx.x; c < 2 * dim; c += LN_THREADS) out[c] = lds[c];
 }
 
-// Stage 2: out[c] (+)= sum_p ws[p][c], in a FIXED order (no atomics: bit-reproducible).  A block owns 16 columns: thread (c, g),
-// g < 16, sums the parts p == g (mod 16) in increasing p, the 16 groups meet in LDS as a fixed tree, the result is stored (or added
-// to what the gradient arena holds) by one thread per column.
+// Stage 2: out[c] (+)= sum_p ws[p][c], in a FIXED order (no atomics: bit-reproducible).  A block owns 4 columns: thread (c, g), g < 64,
+// sums the parts p == g (mod 64) in increasing p (16 independent loads for 1024 parts); the 64 groups meet in LDS and thread c adds
+// them in order 0..63; the result is stored (or added to what the gradient arena holds).
 __global__ __launch_bounds__(256) void ln_bwd_reduce(const float* __restrict__ ws, float* __restrict__ dw, float* __restrict__ db,
                                                      int parts, int dim, int accumulate) {
-  __shared__ float red[16][17];
-  const int cl = threadIdx.x & 15, g = threadIdx.x >> 4;
-  const int c = blockIdx.x * 16 + cl;
+  __shared__ float red[64][4];
+  const int cl = threadIdx.x & 3, g = threadIdx.x >> 2;
+  const int c = blockIdx.x * 4 + cl;
   float s = 0.f;
   if (c < 2 * dim)
-    for (int p = g; p < parts; p += 16) s += ws[(size_t)p * 2 * dim + c];
+    for (int p = g; p < parts; p += 64) s += ws[(size_t)p * 2 * dim + c];
   red[g][cl] = s;
   __syncthreads();
   if (g == 0 && c < 2 * dim) {
-    float t[16];
+    float v = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) t[k] = red[k][cl];
-    const float v = (((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]))) +
-                    (((t[8] + t[9]) + (t[10] + t[11])) + ((t[12] + t[13]) + (t[14] + t[15])));
+    for (int k = 0; k < 64; ++k) v += red[k][cl];
     float* dst = c < dim ? &dw[c] : &db[c - dim];
     *dst = (accumulate ? *dst : 0.f) + v;
   }
@@ -321,6 +319,6 @@ extern "C" int dinox_layernorm_bwd(const void* dy, const float* x, const float* 
 #undef LN_BWD
   int rc = check_launch("layernorm_bwd");
   if (rc) return rc;
-  hipLaunchKernelGGL(ln_bwd_reduce, dim3((unsigned)ceil_div(2 * dim, 16)), dim3(256), 0, st, wsf, dw, db, parts, dim, accumulate ? 1 : 0);
+  hipLaunchKernelGGL(ln_bwd_reduce, dim3((unsigned)ceil_div(2 * dim, 4)), dim3(256), 0, st, wsf, dw, db, parts, dim, accumulate ? 1 : 0);
   return check_launch("layernorm_bwd_reduce");
 }

@@ -78,7 +78,9 @@ class GradBucketer:
     ``flat_grad``.  Call ``arm()`` before backward, ``finish()`` after it (waits for every bucket)."""
 
     def __init__(self, params: Sequence[torch.nn.Parameter], offsets: Sequence[int], flat_grad: torch.Tensor,
-                 bucket_bytes: int = 32 << 20, group=None) -> None:
+                 bucket_bytes: int = 32 << 20, group=None, tail_bytes: int = 4 << 20) -> None:
+        """``tail_bytes``: the bucket that fills LAST (the first parameters of the arena: tokens, patch embedding, the first
+        blocks) cannot hide under backward -- nothing is left to run -- so it is kept small: its all-reduce is the only exposed one."""
         self.flat = flat_grad
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -86,6 +88,7 @@ class GradBucketer:
         self.buckets: List[_Bucket] = []
         self.bucket_of: Dict[int, int] = {}
         cap = max(1, bucket_bytes // flat_grad.element_size())
+        tail = max(1, min(tail_bytes, bucket_bytes) // flat_grad.element_size())
         # walk parameters from last to first; a bucket is a contiguous slice [lo, hi)
         hi = None
         lo = None
@@ -97,7 +100,8 @@ class GradBucketer:
             else:
                 lo = p_lo
                 members.append(i)
-            if hi - lo >= cap or i == 0:
+            # close the bucket when it is full -- or when what is left below it fits the small tail bucket
+            if hi - lo >= cap or i == 0 or (p_lo <= tail and hi - lo > 0 and p_lo > 0 and hi > tail):
                 b = len(self.buckets)
                 self.buckets.append(_Bucket(lo=lo, hi=hi, pending=len(members), n_params=len(members)))
                 for j in members:

@@ -1466,7 +1466,8 @@ def test_graph_replay_matches_eager(dx):
         assert float(((pg - pe).abs() <= 10 * tol * pe.abs() + 2.1e-3).double().mean()) == 1.0
 
 
-@pytest.mark.parametrize("K,M,N,cs", [(102912, 1536, 384, True), (25728, 384, 384, True), (5000, 1152, 384, False), (804 * 32 + 17, 136, 264, True)])
+@pytest.mark.parametrize("K,M,N,cs", [(102912, 1536, 384, True), (25728, 384, 384, True), (5000, 1152, 384, False), (804 * 32 + 17, 136, 264, True),
+                                      (102912, 384, 1536, True), (30000, 1152, 384, True), (100352, 384, 768, False), (9000, 64, 72, True)])
 def test_gemm_tn_split_k_is_bit_reproducible(dx, K, M, N, cs):
     """The dW products (C[M,N] = A[K,M]^T B[K,N], K = every token of the batch) split K over the chip.  With the workspace the host
     side hands them (ops._tn_workspace) the splits meet in a fixed-order two-stage reduction instead of fp32 atomics: five launches
@@ -1486,7 +1487,7 @@ def test_gemm_tn_split_k_is_bit_reproducible(dx, K, M, N, cs):
             ops.gemm(A, B, transA=True, transB=True, out=C, accumulate=True, colsum_out=cvec if cs else None)
             P = ops.gemm(A, B, transA=True, transB=True, out_dtype=torch.float32)
             outs.append((C, cvec, P))
-        assert set(ops.TRACE_KERNELS) == {"gemm_bf16_tn_dma"}
+        assert set(ops.TRACE_KERNELS) == {"gemm_bf16_tn_big" if K >= 8192 else "gemm_bf16_tn_dma"}       # long K: the big-tile form
     finally:
         ops.TRACE_KERNELS = None
     for C, cvec, P in outs[1:]:

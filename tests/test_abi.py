@@ -59,7 +59,8 @@ def test_version_and_error_plumbing():
 def test_gemm_args_struct_layout():
     """sizeof/offsets of the ctypes mirror of dinox_gemm_args follow the C struct (natural alignment)."""
     from dinox._lib import GemmArgs
-    assert ctypes.sizeof(GemmArgs) == 3 * 8 + 3 * 8 + 3 * 8 + 4 * 8 + 5 * 4 + 4 + 2 * 8 + 8 + 8 + 8 + 8
+    assert ctypes.sizeof(GemmArgs) == 3 * 8 + 3 * 8 + 3 * 8 + 4 * 8 + 5 * 4 + 4 + 2 * 8 + 8 + 8 + 8 + 8 + 8        # (+ ws, ABI version 2)
+    assert GemmArgs.ws.offset == ctypes.sizeof(GemmArgs) - 8
     assert GemmArgs.alpha.offset == 13 * 8 + 5 * 4
     assert GemmArgs.bias.offset == 13 * 8 + 24
 

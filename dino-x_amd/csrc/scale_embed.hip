@@ -90,8 +90,21 @@ __global__ __launch_bounds__(SE_THREADS) void scale_embed_bwd_rows(
   }
 }
 
-// parameter gradients: one thread per parameter element, loop over the V rows.
+// parameter gradients: one thread per parameter element, loop over the V rows -- eight rows per trip with eight independent partial
+// sums (fixed order: deterministic), so eight loads are in flight per thread (one dependent add per row: 178 us for 74 KFLOP at V = 512).
 // index space: [0, D*h) dw2 | +D db2 | +3h dw0 | +h db0 | +D dlnw | +D dlnb
+template <typename F>
+__device__ __forceinline__ float se_sum_rows(int V, F term) {
+  float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int v = 0;
+  for (; v + 8 <= V; v += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) p[u] += term(v + u);
+  }
+  for (; v < V; ++v) p[0] += term(v);
+  return ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+}
+
 __global__ __launch_bounds__(256) void scale_embed_bwd_params(
     const float* __restrict__ dout, const float* __restrict__ sp, const float* __restrict__ hact, const float* __restrict__ e,
     const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ de, const float* __restrict__ dhpre,
@@ -99,43 +112,34 @@ __global__ __launch_bounds__(256) void scale_embed_bwd_params(
     float* __restrict__ dlnb, int V, int h, int D) {
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t n_dw2 = (int64_t)D * h;
-  float s = 0.f;
   if (idx < n_dw2) {
     const int dd = (int)(idx / h), j = (int)(idx % h);
-    for (int v = 0; v < V; ++v) s += de[(int64_t)v * D + dd] * hact[(int64_t)v * h + j];
-    dw2[idx] = s;
+    dw2[idx] = se_sum_rows(V, [&](int v) { return de[(int64_t)v * D + dd] * hact[(int64_t)v * h + j]; });
     return;
   }
   idx -= n_dw2;
   if (idx < D) {
-    for (int v = 0; v < V; ++v) s += de[(int64_t)v * D + idx];
-    db2[idx] = s;
+    db2[idx] = se_sum_rows(V, [&](int v) { return de[(int64_t)v * D + idx]; });
     return;
   }
   idx -= D;
   if (idx < 3 * h) {
     const int j = (int)(idx / 3), c = (int)(idx % 3);
-    for (int v = 0; v < V; ++v) s += dhpre[(int64_t)v * h + j] * sp[v * 3 + c];
-    dw0[idx] = s;
+    dw0[idx] = se_sum_rows(V, [&](int v) { return dhpre[(int64_t)v * h + j] * sp[v * 3 + c]; });
     return;
   }
   idx -= 3 * h;
   if (idx < h) {
-    for (int v = 0; v < V; ++v) s += dhpre[(int64_t)v * h + idx];
-    db0[idx] = s;
+    db0[idx] = se_sum_rows(V, [&](int v) { return dhpre[(int64_t)v * h + idx]; });
     return;
   }
   idx -= h;
   if (idx < D) {
-    for (int v = 0; v < V; ++v) s += dout[(int64_t)v * D + idx] * (e[(int64_t)v * D + idx] - mean[v]) * rstd[v];
-    dlnw[idx] = s;
+    dlnw[idx] = se_sum_rows(V, [&](int v) { return dout[(int64_t)v * D + idx] * (e[(int64_t)v * D + idx] - mean[v]) * rstd[v]; });
     return;
   }
   idx -= D;
-  if (idx < D) {
-    for (int v = 0; v < V; ++v) s += dout[(int64_t)v * D + idx];
-    dlnb[idx] = s;
-  }
+  if (idx < D) dlnb[idx] = se_sum_rows(V, [&](int v) { return dout[(int64_t)v * D + idx]; });
 }
 
 }  // namespace dinox

@@ -10,7 +10,8 @@ from conftest import ROOT
 
 
 def _recorded_line():
-    md = open(os.path.join(ROOT, "profiles", "r01_bench_bs256_summary.md")).read()
+    import glob
+    md = open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_bs256_summary.md")))[-1]).read()      # the latest round's record
     sec = md[md.index("Default bench line"):]
     m = re.search(r"```\n(\{.*?\})\n```", sec, re.S)
     assert m, "no default bench line recorded"
@@ -36,5 +37,14 @@ def test_recorded_bench_line_meets_the_contract():
     if r["bound"] == "hbm":
         assert r["achieved"] == pytest.approx(r["hbm"]["algorithmic_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9, rel=2e-3)
     assert r["traffic"] is None or r["traffic"] > 0.5 * r["hbm"]["algorithmic_bytes_per_launch"]
+    if "step_ms_split" in d:                       # round 2 on: phase split (HIP events) and the other single-GPU configs in the same line
+        sp = d["step_ms_split"]
+        assert set(sp) == {"fwd_student", "fwd_teacher", "loss", "bwd", "comm_exposed", "optimiser_tail"} and all(v >= 0 for v in sp.values())
+        assert sum(sp.values()) == pytest.approx(d["ms_per_step"], rel=0.15)
+        sec = d["secondary"]
+        assert {"bs64_scale_off", "multicrop_2g8l", "vit_large_bs128"} <= set(sec)
+        for k, v in sec.items():
+            assert "error" not in v, (k, v)
+            assert v["unit"] == "samples/s" and v["value"] > 0 and v["ms_per_step"] > 0 and v["workload"]
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]

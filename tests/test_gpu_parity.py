@@ -1528,3 +1528,25 @@ def test_training_steps_are_bit_reproducible(dx):
     assert la == lb
     for name, x, y in zip(("student", "teacher", "adam_m", "adam_v", "centre", "last gradient"), a, b):
         assert torch.equal(x, y), f"{name}: {int((x != y).sum())} of {x.numel()} elements differ between two identical runs"
+
+
+def test_bench_launches_its_own_ranks(dx):
+    """`python bench.py --gpus 2` started plainly (no torchrun) spawns its two ranks as child processes itself -- before the parent
+    has touched the GPU -- and relays rank 0's line.  Here both ranks share this box's one GPU over gloo (RCCL wants a GPU per
+    rank); on an 8-GPU node the same command runs one rank per GPU over RCCL."""
+    import json, os, subprocess, sys
+    from conftest import ROOT
+    env = dict(os.environ, DINOX_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch-size", "16",
+                        "--no-cpu-baseline", "--no-secondary"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=400)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-2000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 32 and d["scaling"] == "weak"
+    assert d["value"] == pytest.approx(32 / (d["ms_per_step"] * 1e-3), rel=1e-3) and "cpu_baseline" not in d
+    fired, total = (int(x) for x in d["config"]["grad_buckets_launched_during_backward"].split("/"))
+    assert total >= 3 and fired >= total - 1                 # the all-reduces are launched from backward, not after it
+    assert set(d["step_ms_split"]) == {"fwd_student", "fwd_teacher", "loss", "bwd", "comm_exposed", "optimiser_tail"}

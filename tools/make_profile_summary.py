@@ -11,7 +11,7 @@ prof = os.path.join(ROOT, "profiles")
 
 
 def one(pattern):
-    hits = sorted(glob.glob(os.path.join(src, pattern), recursive=True))
+    hits = sorted(glob.glob(os.path.join(src, pattern), recursive=True), key=os.path.getmtime)       # (gpurun MERGES: older runs' files stay)
     if not hits:
         raise SystemExit(f"missing {pattern} under {src}")
     return hits[-1]
@@ -44,7 +44,7 @@ for r in rows:
 dom = prof_line["roofline"]["kernel"]
 dom_key = next(k for k in fam if k.endswith(dom))
 md = [f"# rocprofv3 --kernel-trace --stats summary, round {tag[1:]}", "",
-      "Command (MI355X, 1 GPU): `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline`",
+      "Command (MI355X, 1 GPU): `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-step-split`",
       f"({steps} optimiser steps of ViT-S/16 224 bs256 = 512 views, bf16 mode, everything on one stream; HIP-event kernel timing active as in the "
       f"default bench run).  Raw CSV: `{tag}_bench_bs256_kernel_stats.csv`.  Regenerate: `tools/refresh_profiles.sh` on the GPU box, then "
       "`tools/make_profile_summary.py`.", "",
@@ -59,14 +59,14 @@ md += ["", f"Total kernel time {total_ns / 1e6:.1f} ms over {steps} steps = {tot
        f"**{prof_line['roofline']['avg_launch_us']} us** (`roofline.avg_launch_us` above).", "",
        "Default bench line (`python bench.py`, unprofiled, with the CPU baseline leg) of the same box:", "", "```", default_line, "```", "",
        "## HBM traffic (separate PMC passes)", "",
-       "`rocprofv3 --pmc FETCH_SIZE -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing` and the same with `--pmc WRITE_SIZE` "
+       "`rocprofv3 --pmc FETCH_SIZE -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-step-split --no-kernel-timing` and the same with `--pmc WRITE_SIZE` "
        f"(never combined with a trace domain); summary by `tools/pmc_summary.py` in `{tag}_pmc_traffic.json` (FETCH_SIZE doubled: gfx950 reports half the "
        "bytes of 16-B/lane streaming reads, MI355X_MICROARCH.md; sanity check: `ln_fwd_kernel` must read its 158 MB fp32 input once).", "",
        "| kernel family | launches | HBM read / launch | HBM write / launch |", "|---|---|---|---|"]
 for k, v in list(pmc.items())[:14]:
     md.append(f"| `{k}` | {v['launches']} | {v['fetch_bytes_per_launch_x2_corrected'] / 1e6:.1f} MB | {v['write_bytes_per_launch'] / 1e6:.1f} MB |")
 md.append("")
-sq = sorted(glob.glob(os.path.join(src, "pmc_sq/**/*_counter_collection.csv"), recursive=True))
+sq = sorted(glob.glob(os.path.join(src, "pmc_sq/**/*_counter_collection.csv"), recursive=True), key=os.path.getmtime)
 mfma_json = os.path.join(prof, f"{tag}_pmc_mfma.json")
 if sq:
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_mfma.py"), sq[-1], mfma_json], check=True, stdout=subprocess.DEVNULL)
@@ -74,7 +74,7 @@ if os.path.exists(mfma_json):
     mf = json.load(open(mfma_json))
     md += ["## MFMA-pipe utilisation and wave states (separate SQ counter pass)", "",
            "`rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -- python bench.py "
-           f"--steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing`; summary by `tools/pmc_mfma.py` in `{tag}_pmc_mfma.json`.  MFMA utilisation = "
+           f"--steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-step-split --no-kernel-timing`; summary by `tools/pmc_mfma.py` in `{tag}_pmc_mfma.json`.  MFMA utilisation = "
            "SQ_VALU_MFMA_BUSY_CYCLES / (dispatch duration x 2.03 GHz x 1024 SIMDs); wave states are fractions of SQ_WAVE_CYCLES (parked = s_waitcnt / "
            "barrier, issue-stalled = an instruction is ready but cannot issue, issuing = an instruction issues).", "",
            "| kernel family | launches | MFMA utilisation | parked | issue-stalled | issuing |", "|---|---|---|---|---|---|"]

@@ -1550,3 +1550,54 @@ def test_bench_launches_its_own_ranks(dx):
     fired, total = (int(x) for x in d["config"]["grad_buckets_launched_during_backward"].split("/"))
     assert total >= 3 and fired >= total - 1                 # the all-reduces are launched from backward, not after it
     assert set(d["step_ms_split"]) == {"fwd_student", "fwd_teacher", "loss", "bwd", "comm_exposed", "optimiser_tail"}
+
+
+def test_full_size_step_properties(dx):
+    """The headline workload itself (ViT-S/16 224, scale-aware, 256 samples = 512 views per step, bf16) -- too big for the CPU oracle, so it
+    is held to size-independent properties:
+      * determinism: two runs of two optimiser steps from the same state end bit-identical (weights, Adam moments, centre);
+      * batch additivity: with the centre frozen (momentum 1) and accumulation_steps = 2, two half batches of 128 samples give the
+        optimiser the gradient of the mean loss over all 256 -- so ONE optimiser step taken that way must land where the plain
+        bs-256 step lands (to bf16 / summation-order round-off), and the logged quantities must be finite and sane
+        (loss below the entropy wall ln 8192 + Gram term, every weight moved by at most lr)."""
+    ops, arch = dx
+    from dinox.engine import StepHyperParams, TrainEngine
+    kw = dict(img_size=224, patch=16, dim=384, depth=12, heads=6, num_registers=4, scale_aware=True)
+    torch.manual_seed(0)
+    ref = arch.DinoStudentTeacher(arch.PatchViT(**kw), 8192)
+    torch.nn.init.xavier_uniform_(ref.backbone.scale_embed.mlp[2].weight)
+    sd = {k: v.clone() for k, v in ref.state_dict().items()}
+    del ref
+    g = torch.Generator().manual_seed(1)
+    B = 256
+    v1, v2 = torch.randn(B, 3, 224, 224, generator=g), torch.randn(B, 3, 224, 224, generator=g)
+    sp = torch.rand(B, 3, generator=g) * 0.5 + 0.5
+    full = (torch.cat([v1, v2], 0).to(DEV), torch.cat([sp, sp], 0).to(DEV))
+    halves = [(torch.cat([v1[i:i + 128], v2[i:i + 128]], 0).to(DEV), torch.cat([sp[i:i + 128], sp[i:i + 128]], 0).to(DEV)) for i in (0, 128)]
+    del v1, v2
+
+    def run(batches, accum, steps):
+        student = arch.DinoStudentTeacher(arch.PatchViT(**kw), 8192)
+        teacher = arch.DinoStudentTeacher(arch.PatchViT(**kw), 8192)
+        student.load_state_dict(sd)
+        teacher.load_state_dict(sd)
+        eng = TrainEngine(student.to(DEV), teacher.to(DEV), 8192, StepHyperParams(lr=1e-3, warmup_steps=1, max_steps=10, ema=0.99, center_momentum=1.0),
+                          amp_dtype=torch.bfloat16, accumulation_steps=accum)
+        for _ in range(steps):
+            for b, s in batches:
+                eng.step(b, s)
+        sc = eng.scalars()
+        return eng.flat_p.clone(), eng.adam_m.clone(), eng.center.clone(), sc
+
+    p1, m1, c1, s1 = run([full], 1, 2)
+    p2, m2, c2, s2 = run([full], 1, 2)
+    assert torch.equal(p1, p2) and torch.equal(m1, m2) and torch.equal(c1, c2) and s1 == s2
+    assert math.isfinite(s1["loss"]) and 0 < s1["loss"] < math.log(8192) + 2.0 and math.isfinite(s1["grad_norm"]) and s1["grad_norm"] > 0
+    pa, ma, _, _ = run([full], 1, 1)
+    pb, mb, _, sb = run(halves, 2, 1)
+    p0 = torch.cat([v.reshape(-1) for v in sd.values()])          # (not arena order -- only used for the size of the update below)
+    assert float((pa - pb).abs().max()) <= 2.1e-3                  # an Adam step moves a weight by at most lr (sign noise on ~zero gradients)
+    moved = (pa - pb).abs()
+    assert float((moved <= 2e-5).double().mean()) > 0.97           # ... and almost all of them land on the same value
+    assert rel_l2(mb, ma) < 2e-2                                   # first moments = 0.1 x gradient: the two gradients agree to bf16 round-off
+    assert p0.numel() <= pa.numel()

@@ -20,8 +20,9 @@
 // launches it replaces); a row's sum and M2 over the wave's 96 columns are 48 lane-local terms + one exchange with lane ^ 32
 // (two passes over registers: exact, no E[x^2] - mean^2 cancellation); the four column-waves of a row meet through 8 bytes of LDS
 // per wave and row and ONE workgroup barrier per tile and merge by Chan's formula (equal counts: mean = avg of means, M2 = sum M2
-// + 96 sum (mean_w - mean)^2); y = (x - mean) rstd gamma + beta is packed to bf16 and widened to 16-byte stores by
-// v_permlane32_swap (guide T21: lanes i / i + 32 hold columns 8k..8k+3 / 8k+4..8k+7 of the same row).
+// + 96 sum (mean_w - mean)^2).  Global traffic of the epilogue (residual in, x out, y out) passes through a 4-KiB per-wave LDS tile so
+// that memory sees whole 128-byte lines (second version; the first let every lane load / store its own 16-byte pieces: 32 rows x 32
+// bytes per instruction, 49 of 164 us for the residual loads alone).
 #include "common.h"
 #include "gemm_common.h"
 
@@ -128,44 +129,73 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16_rowln(RowLnParams p) {
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                          // every wave has left the ring: it becomes the epilogue's staging area
 
   // ---- epilogue.  acc[i][j][r]: token row wr*64 + i*32 + frow, feature wc*96 + j*32 + 8*(r >> 2) + 4*fh + (r & 3).
-  // Every global access is (wave-uniform 64-bit base in SGPRs) + (32-bit per-lane offset) + (immediate).
+  // The accumulators hold a token ROW per lane, which is what the LayerNorm statistics want -- but memory wants whole 128-byte
+  // lines: a lane reading / writing its own 16-byte pieces touches 32 rows x 32 bytes per instruction (measured: 49 of 164 us for
+  // the residual loads alone).  So every [32 rows][32 columns] block passes through a 4-KiB per-wave LDS tile ([row][eight 16-byte
+  // chunks], chunk ^ (row & 7)): residual in by coalesced loads (eight lanes = one 128-byte line) and read back row-per-lane;
+  // x out written row-per-lane and read back coalesced; y (bf16) likewise with 64-byte rows.
   float2* const stat = reinterpret_cast<float2*>(smem + RL_STAT);
+  char* const stg = smem + wv * 4096;
   const int64_t mw = m0 + wr * 64;
-  const int colq = wc * 96 + 4 * fh;                                                // + j*32 + 8*g: the lane's runs of 4 columns
   const int nrows = (int)(p.M - mw < 0 ? 0 : (p.M - mw > 64 ? 64 : p.M - mw));     // valid rows of the wave's 64-row block (uniform)
   const int64_t mwl = nrows > 0 ? mw : p.M - 1;                                    // loads stay inside the tensors
-  const char* const rbase = (const char*)(p.residual ? p.residual + mwl * RL_BN : p.x_out);
-  char* const xbase = (char*)(p.x_out + mw * RL_BN);
-  char* const ybase = (char*)p.y + mw * RL_BN * (Y_DT == DINOX_BF16 ? 2 : 4);
+  const char* const rbase = (const char*)(p.residual ? p.residual + mwl * RL_BN : p.x_out) + wc * 96 * 4;
+  char* const xbase = (char*)(p.x_out + mw * RL_BN) + wc * 96 * 4;
+  char* const ybase = (char*)p.y + (mw * RL_BN + wc * 96) * (Y_DT == DINOX_BF16 ? 2 : 4);
   const bool has_res = p.residual != nullptr;
+  const int cr = lane >> 3, cc = lane & 7;                               // coalesced side: row cr + 8 q, chunk cc
+  const int rowl = frow;                                                 // row-per-lane side: row frow, chunks 2 g + fh
+  unsigned rp_off[4];                                                    // this lane's four chunk addresses in the staging tile
+#pragma unroll
+  for (int g = 0; g < 4; ++g) rp_off[g] = (unsigned)(rowl * 128 + (((2 * g + fh) ^ (rowl & 7)) << 4));
+  const float* const bias_s = vec_s + wc * 96;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int r = i * 32 + frow;                                          // row inside the wave's block
-    const bool live = r < nrows;
-    const int rl = live ? r : (nrows > 0 ? nrows - 1 : 0);
-    const unsigned loff = (unsigned)((rl * RL_BN + colq) * 4);
-    const unsigned soff = (unsigned)((r * RL_BN + colq) * 4);
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      float4 rr[4];
+      // residual block in
+      float4 rin[4];
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
-        rr[g] = has_res ? *reinterpret_cast<const float4*>(rbase + loff + (j * 32 + 8 * g) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int q = 0; q < 4; ++q) {
+        const int r = i * 32 + 8 * q + cr;
+        const int rl = r < nrows ? r : (nrows > 0 ? nrows - 1 : 0);
+        rin[q] = has_res ? *reinterpret_cast<const float4*>(rbase + (unsigned)((rl * RL_BN + j * 32 + cc * 4) * 4)) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int rt = 8 * q + cr;
+        *reinterpret_cast<float4*>(stg + rt * 128 + ((cc ^ (rt & 7)) << 4)) = rin[q];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const float4 b4 = *reinterpret_cast<const float4*>(vec_s + colq + j * 32 + 8 * g);
-        const float x0 = acc[i][j][4 * g] + b4.x + rr[g].x, x1 = acc[i][j][4 * g + 1] + b4.y + rr[g].y;
-        const float x2 = acc[i][j][4 * g + 2] + b4.z + rr[g].z, x3 = acc[i][j][4 * g + 3] + b4.w + rr[g].w;
+        const float4 r4 = *reinterpret_cast<const float4*>(stg + rp_off[g]);
+        const float4 b4 = *reinterpret_cast<const float4*>(bias_s + j * 32 + 8 * g + 4 * fh);
+        const float x0 = acc[i][j][4 * g] + b4.x + r4.x, x1 = acc[i][j][4 * g + 1] + b4.y + r4.y;
+        const float x2 = acc[i][j][4 * g + 2] + b4.z + r4.z, x3 = acc[i][j][4 * g + 3] + b4.w + r4.w;
         acc[i][j][4 * g] = x0;
         acc[i][j][4 * g + 1] = x1;
         acc[i][j][4 * g + 2] = x2;
         acc[i][j][4 * g + 3] = x3;
         s += (x0 + x1) + (x2 + x3);
-        if (live) *reinterpret_cast<float4*>(xbase + soff + (j * 32 + 8 * g) * 4) = make_float4(x0, x1, x2, x3);
+        *reinterpret_cast<float4*>(stg + rp_off[g]) = make_float4(x0, x1, x2, x3);          // same chunk this lane has just read
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      // x block out
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int rt = 8 * q + cr, r = i * 32 + rt;
+        const float4 v = *reinterpret_cast<const float4*>(stg + rt * 128 + ((cc ^ (rt & 7)) << 4));
+        if (r < nrows) *reinterpret_cast<float4*>(xbase + (unsigned)((r * RL_BN + j * 32 + cc * 4) * 4)) = v;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();                                    // the tile is refilled by the next block
     }
     s += __shfl_xor(s, 32, 64);                                           // the other 48 columns of the wave's 96
     const float mw_ = s * (1.0f / 96.0f);
@@ -178,52 +208,61 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16_rowln(RowLnParams p) {
         m2 += d * d;
       }
     m2 += __shfl_xor(m2, 32, 64);
-    if (fh == 0) stat[(wr * 64 + r) * 4 + wc] = make_float2(mw_, m2);
+    if (fh == 0) stat[(wr * 64 + i * 32 + frow) * 4 + wc] = make_float2(mw_, m2);
   }
   __syncthreads();                                                        // the four column-waves of every row have written
+  const float* const gam_s = vec_s + RL_BN + wc * 96;
+  const float* const bet_s = vec_s + 2 * RL_BN + wc * 96;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int r = i * 32 + frow;
-    const bool live = r < nrows;
-    const unsigned soff = (unsigned)((r * RL_BN + colq) * 4);
     const float4 s01 = *reinterpret_cast<const float4*>(stat + (wr * 64 + r) * 4);
     const float4 s23 = *reinterpret_cast<const float4*>(stat + (wr * 64 + r) * 4 + 2);
     const float mean = 0.25f * ((s01.x + s01.z) + (s23.x + s23.z));
     const float d0 = s01.x - mean, d1 = s01.z - mean, d2 = s23.x - mean, d3 = s23.z - mean;
     const float var = ((s01.y + s01.w) + (s23.y + s23.w) + 96.0f * ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3))) * (1.0f / 384.0f);
     const float rstd = rsqrtf(var + p.eps);
-    if (live && wc == 0 && fh == 0) {
+    if (r < nrows && wc == 0 && fh == 0) {
       p.mean[mw + r] = mean;
       p.rstd[mw + r] = rstd;
     }
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      unsigned pk[4][2];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const float4 g4 = *reinterpret_cast<const float4*>(vec_s + RL_BN + colq + j * 32 + 8 * g);
-        const float4 b4 = *reinterpret_cast<const float4*>(vec_s + 2 * RL_BN + colq + j * 32 + 8 * g);
+        const float4 g4 = *reinterpret_cast<const float4*>(gam_s + j * 32 + 8 * g + 4 * fh);
+        const float4 b4 = *reinterpret_cast<const float4*>(bet_s + j * 32 + 8 * g + 4 * fh);
         const float y0 = (acc[i][j][4 * g] - mean) * rstd * g4.x + b4.x, y1 = (acc[i][j][4 * g + 1] - mean) * rstd * g4.y + b4.y;
         const float y2 = (acc[i][j][4 * g + 2] - mean) * rstd * g4.z + b4.z, y3 = (acc[i][j][4 * g + 3] - mean) * rstd * g4.w + b4.w;
         if (Y_DT == DINOX_BF16) {
-          pk[g][0] = (unsigned)f32_to_bf16(y0) | ((unsigned)f32_to_bf16(y1) << 16);
-          pk[g][1] = (unsigned)f32_to_bf16(y2) | ((unsigned)f32_to_bf16(y3) << 16);
-        } else if (live) {
-          *reinterpret_cast<float4*>(ybase + soff + (j * 32 + 8 * g) * 4) = make_float4(y0, y1, y2, y3);
+          uint2 pk;
+          pk.x = (unsigned)f32_to_bf16(y0) | ((unsigned)f32_to_bf16(y1) << 16);
+          pk.y = (unsigned)f32_to_bf16(y2) | ((unsigned)f32_to_bf16(y3) << 16);
+          // bf16 tile: 64-byte rows, four 16-byte chunks; this lane's 8 bytes are half fh of chunk g
+          *reinterpret_cast<uint2*>(stg + rowl * 64 + ((g ^ (rowl & 3)) << 4) + 8 * fh) = pk;
+        } else {
+          *reinterpret_cast<float4*>(stg + rp_off[g]) = make_float4(y0, y1, y2, y3);
         }
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
       if (Y_DT == DINOX_BF16) {
-        // lanes i / i + 32 hold columns 8g..8g+3 / 8g+4..8g+7: one half-exchange per dword and pair of groups gives the lower
-        // lane columns 8g..8g+7 and the upper lane 8g+8..8g+15 -> one 16-byte store each (guide T21)
 #pragma unroll
-        for (int g = 0; g < 4; g += 2) {
-          const auto e0 = __builtin_amdgcn_permlane32_swap(pk[g][0], pk[g + 1][0], false, false);
-          const auto e1 = __builtin_amdgcn_permlane32_swap(pk[g][1], pk[g + 1][1], false, false);
-          const rl_u32x4 out = {e0[0], e1[0], e0[1], e1[1]};
-          // byte offset of column (wc*96 + j*32 + 8g) in a bf16 row, + 16 for the upper lanes; soff/2 = (r*384 + wc*96 + 4fh)*2
-          if (live) *reinterpret_cast<rl_u32x4*>(ybase + (soff >> 1) - 8 * fh + 16 * fh + (j * 32 + 8 * g) * 2) = out;
+        for (int q = 0; q < 2; ++q) {
+          const int rt = 16 * q + (lane >> 2), c4 = lane & 3, rr = i * 32 + rt;
+          const rl_u32x4 v = *reinterpret_cast<const rl_u32x4*>(stg + rt * 64 + ((c4 ^ (rt & 3)) << 4));
+          if (rr < nrows) *reinterpret_cast<rl_u32x4*>(ybase + (unsigned)((rr * RL_BN + j * 32 + c4 * 8) * 2)) = v;
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int rt = 8 * q + cr, rr = i * 32 + rt;
+          const float4 v = *reinterpret_cast<const float4*>(stg + rt * 128 + ((cc ^ (rt & 7)) << 4));
+          if (rr < nrows) *reinterpret_cast<float4*>(ybase + (unsigned)((rr * RL_BN + j * 32 + cc * 4) * 4)) = v;
         }
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
   }
 }

@@ -373,13 +373,17 @@ def layernorm_fwd(x: Tensor, w: Tensor, b: Tensor, out_dtype: torch.dtype, eps: 
     return y, mean, rstd
 
 
+_ROWLN = os.environ.get("DINOX_ROWLN")          # "1": every width-384 product, "0": none, unset: the short reductions (proj) only
+
+
 def rowln_ok(M: int, N: int, K: int, dt: torch.dtype) -> bool:
     """Should this product + the LayerNorm behind it run as ONE launch (csrc/gemm_bf16_rowln.hip; bf16 mode, N = 384)?
-    OPT-IN (DINOX_ROWLN=1).  Measured on MI355X at the hot-path shape (M = 102 912): proj + LN 164 us fused against 89 + 50 us for
-    the two launches, fc2 + LN 280 us against 197 + 50; whole step 44.25 ms against 42.11 ms.  The fused kernel moves 20 % fewer
-    bytes but its row-per-lane epilogue reaches HBM in 16-byte pieces (ablation: 49 us of the 164 are the residual loads alone),
-    and its two-slot 128 x 384 K loop is slower than the 128 x 128 kernels' at K = 1536 (185 us with no epilogue traffic at all)."""
-    return dt == torch.bfloat16 and bool(os.environ.get("DINOX_ROWLN")) and bool(lib.dinox_linear_residual_ln_ok(M, N, K))
+    Measured on MI355X at the hot-path shape (M = 102 912), with the epilogue traffic staged through LDS as whole 128-byte lines:
+    proj + LN 136 us fused against 95 + 52 us for the two launches -> on by default for short reductions (K <= 576);
+    fc2 + LN 272 us against 213 + 52 us (its two-slot 128 x 384 K loop alone takes 185 us at K = 1536) -> off unless DINOX_ROWLN=1."""
+    if dt != torch.bfloat16 or _ROWLN == "0" or not lib.dinox_linear_residual_ln_ok(M, N, K):
+        return False
+    return _ROWLN == "1" or K <= 576
 
 
 def linear_residual_ln(a: Tensor, w: Tensor, bias: Optional[Tensor], residual: Optional[Tensor], gamma: Tensor, beta: Tensor, eps: float,

@@ -34,9 +34,10 @@ typedef unsigned rl_u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int RL_BM = 128, RL_BN = 384, RL_BK = 32;
 constexpr int RL_ATILE = RL_BM * 64, RL_BTILE = RL_BN * 64, RL_SLOT = RL_ATILE + RL_BTILE;       // 8 + 24 = 32 KiB
-constexpr int RL_VEC = 2 * RL_SLOT;                 // bias | gamma | beta slices (3 x 384 floats)
-constexpr int RL_STAT = RL_VEC + 3 * RL_BN * 4;     // [128 rows][4 column-waves] x (mean, M2)
-constexpr int RL_LDS = RL_STAT + RL_BM * 4 * 8;     // 64 KiB + 4.5 KiB + 4 KiB
+// LDS: ring of NS slots | bias, gamma, beta slices (3 x 384 floats) | [128 rows][4 column-waves] x (mean, M2)
+constexpr int rl_vec(int ns) { return ns * RL_SLOT; }
+constexpr int rl_stat(int ns) { return rl_vec(ns) + 3 * RL_BN * 4; }
+constexpr int rl_lds(int ns) { return rl_stat(ns) + RL_BM * 4 * 8; }            // NS = 2: 72.5 KiB (two workgroups per CU); NS = 4: 136.5 KiB
 
 struct RowLnParams {
   const bf16_t* A;       // [M][K]
@@ -54,8 +55,11 @@ struct RowLnParams {
   float eps;
 };
 
-template <int Y_DT>
-__global__ __launch_bounds__(512, 4) void gemm_bf16_rowln(RowLnParams p) {
+// NS = 2: two-slot ring, two workgroups per CU (short reductions: proj).  NS = 4: four-slot ring with counted waits, three K-steps
+// (96 KiB) in flight, one workgroup per CU (long reductions: fc2) -- the two-slot loop alone takes 185 us at K = 1536.
+template <int Y_DT, int NS>
+__global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void gemm_bf16_rowln(RowLnParams p) {
+  constexpr int RL_VEC = rl_vec(NS), RL_STAT = rl_stat(NS);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -98,14 +102,23 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16_rowln(RowLnParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   const int nk = p.K / RL_BK, frow = lane & 31, fh = lane >> 5;
-  stage(0, 0);
+  for (int s0 = 0; s0 < NS - 1 && s0 < nk; ++s0) stage(s0, s0);
   for (int kt = 0; kt < nk; ++kt) {
-    const int slot = kt & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this step's pieces (and, at kt = 0, the vector loads)
+    const int slot = kt & (NS - 1);
+    // this step's pieces have landed (at kt = 0 also the vector loads); with NS = 4 the two younger stages (4 instructions per wave
+    // each) may stay in flight
+    if (NS == 2) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      const int younger = nk - 1 - kt;
+      if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the previous step's fragment reads: its slot is refilled below
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (kt + 1 < nk) stage(slot ^ 1, kt + 1);
+    if (kt + NS - 1 < nk) stage((kt + NS - 1) & (NS - 1), kt + NS - 1);
     const char* sa = smem + slot * RL_SLOT;
     const char* sb = sa + RL_ATILE;
 #pragma unroll
@@ -288,12 +301,17 @@ extern "C" int dinox_linear_residual_ln(const void* a, const void* w, const floa
   RowLnParams p{(const bf16_t*)a, (const bf16_t*)w, bias, residual, x_out, gamma, beta, y, mean, rstd, M, K, eps};
   const unsigned tiles = (unsigned)ceil_div(M, (int64_t)RL_BM);
   hipStream_t st = as_stream(stream);
+#define RL_LAUNCH(YDT, NS)                                                                                                        \
+  do {                                                                                                                            \
+    if (int rc = reserve_lds(reinterpret_cast<const void*>(gemm_bf16_rowln<YDT, NS>), rl_lds(NS), "linear_residual_ln")) return rc; \
+    hipLaunchKernelGGL((gemm_bf16_rowln<YDT, NS>), dim3(tiles), dim3(512), rl_lds(NS), st, p);                                   \
+  } while (0)
+  const bool deep = K > 576;
   if (y_dtype == DINOX_BF16) {
-    if (int rc = reserve_lds(reinterpret_cast<const void*>(gemm_bf16_rowln<DINOX_BF16>), RL_LDS, "linear_residual_ln")) return rc;
-    hipLaunchKernelGGL(gemm_bf16_rowln<DINOX_BF16>, dim3(tiles), dim3(512), RL_LDS, st, p);
+    if (deep) RL_LAUNCH(DINOX_BF16, 4); else RL_LAUNCH(DINOX_BF16, 2);
   } else {
-    if (int rc = reserve_lds(reinterpret_cast<const void*>(gemm_bf16_rowln<DINOX_F32>), RL_LDS, "linear_residual_ln")) return rc;
-    hipLaunchKernelGGL(gemm_bf16_rowln<DINOX_F32>, dim3(tiles), dim3(512), RL_LDS, st, p);
+    if (deep) RL_LAUNCH(DINOX_F32, 4); else RL_LAUNCH(DINOX_F32, 2);
   }
+#undef RL_LAUNCH
   return check_launch("linear_residual_ln");
 }

@@ -105,6 +105,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short measurements of the other single-GPU configs")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket GEMM launches with HIP events")
+    ap.add_argument("--time-every", type=int, default=16, help="bracket one GEMM launch in this many with HIP events (1: all; costs ~6 %% of the step)")
     ap.add_argument("--no-step-split", action="store_true", help="skip the extra steps that time the phases of the step (profiler runs)")
     return ap.parse_args(argv)
 
@@ -192,9 +193,13 @@ def timed(wl, steps, warmup, barrier, note=None, timer=None):
     t0 = time.perf_counter()
     for _ in range(steps):
         wl.step()
+    t_enq = time.perf_counter() - t0          # host side done enqueueing; the device may still be running
     barrier()
     dt = time.perf_counter() - t0
     ops.GEMM_TIMER = None
+    if note:
+        note(f"host enqueue {1e3 * t_enq / max(steps, 1):.2f} ms/step of {1e3 * dt / max(steps, 1):.2f} ms/step")
+    timed.host_enqueue_ms = 1e3 * t_enq / max(steps, 1)
     return dt
 
 
@@ -266,7 +271,7 @@ def main() -> None:
     wl = Workload(dev, rank, model=args.model, B=B, scale_aware=not args.no_scale_aware, L=L, local_size=args.local_size, fp32=args.fp32,
                   steps_hint=args.steps + args.warmup + 8, graph=args.graph)
     note(f"model + data resident (world {world}, B {B}/GPU, {'fp32' if args.fp32 else 'bf16'})")
-    timer = None if (args.no_kernel_timing or args.graph) else ops.GemmTimer()
+    timer = None if (args.no_kernel_timing or args.graph) else ops.GemmTimer(every=args.time_every)
     dt = timed(wl, args.steps, args.warmup, barrier, note, timer)
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -303,7 +308,7 @@ def main() -> None:
                 roof.update(bound="hbm", achieved=hbm["achieved"], peak=PEAK_HBM_GBS, unit="GB/s", frac=hbm["frac"], mfma=mfma, hbm=hbm)
             else:
                 roof.update(bound="mfma", achieved=mfma["achieved"], frac=mfma["frac"], mfma=mfma, hbm=hbm)
-            roof.update(kernel=dom, launches_per_step=d["launches"] // args.steps, avg_launch_us=round(1e3 * d["ms"] / d["launches"], 2),
+            roof.update(kernel=dom, launches_per_step=d["launches"] // args.steps, timed_launches=d["timed"], avg_launch_us=round(1e3 * d["ms"] / d["launches"], 2),
                         kernel_share_of_step=round(d["ms"] / (dt * 1e3), 4),
                         all_gemm_kernels={k: {"launches": v["launches"], "ms": round(v["ms"], 3),
                                               "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
@@ -334,7 +339,7 @@ def main() -> None:
             "config": {"workload": ("ViT-S" if args.model == "vit-small" else "ViT-L") + f"/16 224x224x3 2.5D slice stacks, "
                                    f"{'scale-aware' if not args.no_scale_aware else 'scale-aware off'}, {views}, DINO+Gram loss, AdamW+EMA",
                        "per_gpu_batch": B, "global_batch": B * world, "views_per_step": (2 + L) * B * world, "local_crops": L, "tokens": 201, "out_dim": wl.out_dim,
-                       "parallelism": f"dp{world}", "views_per_s": round((2 + L) * samples_s, 2), "hipgraph": bool(args.graph),
+                       "parallelism": f"dp{world}", "views_per_s": round((2 + L) * samples_s, 2), "hipgraph": bool(args.graph), "host_enqueue_ms_per_step": round(timed.host_enqueue_ms, 2),
                        "loss": round(scal["loss"], 5), "grad_norm": round(scal["grad_norm"], 5)},
             "roofline": roof,
             "step_ms_split": split,

@@ -82,12 +82,18 @@ def _c(t: Tensor) -> Tensor:
 
 
 class GemmTimer:
-    """Optional per-launch timing of dinox_gemm with HIP events recorded on the launch stream
-    (bench.py installs one over its timed region to price the dominant kernel against the MFMA
-    roofline).  Keyed by the kernel the dispatcher picks (dinox_gemm_kernel_name)."""
+    """Optional timing of dinox_gemm launches with HIP events recorded on the launch stream (bench.py installs one over
+    its timed region to price the dominant kernel against its roofline).  Keyed by the kernel the dispatcher picks
+    (dinox_gemm_kernel_name).  Every launch is COUNTED (launches, algorithmic flops and bytes); one launch in `every` is
+    TIMED -- an event pair per launch costs the timed region ~6 % at bs 256 (two marker packets around each of ~300
+    launches per step keep the next kernel from starting under the previous one's tail), which a 1-in-16 sample brings
+    under 0.5 %.  The pick is a fixed multiplicative hash of the launch counter, so every position of the step is reached
+    over a few steps; a family's time is the sum over its shapes of (mean timed duration of the shape) x (its launches)."""
 
-    def __init__(self) -> None:
-        self.records = []      # (kernel name, algorithmic flops, start event, end event)
+    def __init__(self, every: int = 16) -> None:
+        self.every = max(1, int(every))
+        self.n = 0
+        self.shapes: dict = {}   # (kernel, M, N, K, batch, epilogue) -> [launches, flops, bytes, [(e0, e1), ...]]
         self.pool = []
 
     def _event(self):
@@ -113,23 +119,49 @@ class GemmTimer:
 
     def launch(self, g, stream) -> None:
         name = lib.dinox_gemm_kernel_name(C.byref(g)).decode()
-        e0, e1 = self._event(), self._event()
-        e0.record()
-        check(lib.dinox_gemm(C.byref(g), stream), "dinox_gemm")
-        e1.record()
-        self.records.append((name, 2.0 * g.M * g.N * g.K * g.batch, self.algorithmic_bytes(g), e0, e1))
+        rec = self.shapes.setdefault((name, g.M, g.N, g.K, g.batch, g.epilogue), [0, 0.0, 0.0, []])
+        rec[0] += 1
+        rec[1] += 2.0 * g.M * g.N * g.K * g.batch
+        rec[2] += self.algorithmic_bytes(g)
+        self.n += 1
+        if self.every == 1 or ((self.n * 2654435761) & 0xFFFFFFFF) * self.every >> 32 == 0:
+            e0, e1 = self._event(), self._event()
+            e0.record()
+            check(lib.dinox_gemm(C.byref(g), stream), "dinox_gemm")
+            e1.record()
+            rec[3].append((e0, e1))
+        else:
+            check(lib.dinox_gemm(C.byref(g), stream), "dinox_gemm")
 
     def summary(self) -> dict:
-        """{kernel: {"launches", "flops", "bytes", "ms"}} -- call after a device synchronise."""
+        """{kernel: {"launches", "timed", "flops", "bytes", "ms"}} -- call after a device synchronise.  "ms" is the family's
+        time over ALL its launches, estimated from the timed ones (see the class docstring)."""
         out: dict = {}
-        for name, fl, by, e0, e1 in self.records:
-            d = out.setdefault(name, {"launches": 0, "flops": 0.0, "bytes": 0.0, "ms": 0.0})
-            d["launches"] += 1
+        untimed = []
+        for (name, *_), (launches, fl, by, evs) in self.shapes.items():
+            d = out.setdefault(name, {"launches": 0, "timed": 0, "flops": 0.0, "bytes": 0.0, "ms": 0.0, "_tb": 0.0, "_tms": 0.0})
+            d["launches"] += launches
             d["flops"] += fl
             d["bytes"] += by
-            d["ms"] += e0.elapsed_time(e1)
-            self.pool += [e0, e1]
-        self.records = []
+            if evs:
+                ms = sum(e0.elapsed_time(e1) for e0, e1 in evs)
+                d["timed"] += len(evs)
+                d["ms"] += ms / len(evs) * launches
+                d["_tb"] += by / launches * len(evs)
+                d["_tms"] += ms
+                for pair in evs:
+                    self.pool += pair
+            else:
+                untimed.append((name, by))
+        for name, by in untimed:          # a shape the sample never reached: the family's measured time per algorithmic byte
+            d = out[name]
+            if d["_tb"] > 0:
+                d["ms"] += by * d["_tms"] / d["_tb"]
+        for name in [k for k, d in out.items() if d["timed"] == 0]:
+            del out[name]
+        for d in out.values():
+            del d["_tb"], d["_tms"]
+        self.shapes = {}
         return out
 
 

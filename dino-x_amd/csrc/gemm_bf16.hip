@@ -313,16 +313,8 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_bf16_tn(GemmParams p, int 
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 
-// PF > 0: a FIFTH wave runs PF K-steps ahead of the four computing waves and touches every 64-byte sector of the slabs they will
-// stage (one dword per sector, LDS-DMA into a scratch corner: no VGPR is written, nothing waits for it).  Why: the staging
-// queue of a wave retires in order and a K-step ends at a barrier, so ONE sector that has to come from HBM holds the whole
-// 32 KB step for an HBM round trip (~1.5-2 us under load) although four fifths of its bytes are L2 hits -- the LDS pipeline then
-// runs at bytes-in-flight / HBM latency (64 KB per CU / 1.4 us = 12 TB/s over the chip: the "40-50 GB/s per CU whatever the kernel
-// does" of round 1) instead of L2 speed.  The prefetcher has its own queue: it pays the HBM latency PF steps early, the computing
-// waves find their sectors in L2.
-template <int OUT_DT, int PF>
-__global__ __launch_bounds__(GB_THREADS + (PF ? 64 : 0), 2) void gemm_bf16_tn_dma(GemmParams p, int tiles_m, int tiles_n, int splits,
-                                                                             int64_t k_per_split, int pf_dist) {
+template <int OUT_DT>
+__global__ __launch_bounds__(GB_THREADS, 2) void gemm_bf16_tn_dma(GemmParams p, int tiles_m, int tiles_n, int splits, int64_t k_per_split) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int wr = wv >> 1, wc = wv & 1;
@@ -393,31 +385,6 @@ __global__ __launch_bounds__(GB_THREADS + (PF ? 64 : 0), 2) void gemm_bf16_tn_dm
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)(sb + q * 1024), 16, voffB[q] + kt * stepB, 0, 0, 0);
     }
   };
-  if (PF && wvu == 4) {
-    // lane -> (row = lane >> 2 of 16, sector = lane & 3 of the 256-byte row piece); four instructions cover the 64 rows of a slab
-    char* const dump = smem + 4 * GB_TILE_BYTES;
-    const int r = lane >> 2, sec = lane & 3;
-    int64_t ma = m0 + sec * 32, nb = n0 + sec * 32;
-    ma = ma < p.M ? ma : p.M - 8;
-    nb = nb < p.N ? nb : p.N - 8;
-    const unsigned pa = (unsigned)(((kbeg + r) * p.lda + ma) * 2), pb = (unsigned)(((kbeg + r) * p.ldb + nb) * 2);
-    const unsigned rowsA = (unsigned)(16 * p.lda * 2), rowsB = (unsigned)(16 * p.ldb * 2);
-    auto touch = [&](int kt) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)dump, 4, pa + kt * stepA + q * rowsA, 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)dump, 4, pb + kt * stepB + q * rowsB, 0, 0, 0);
-      }
-    };
-    for (int kt = 1; kt <= pf_dist && kt < nk; ++kt) touch(kt);
-    __builtin_amdgcn_s_barrier();
-    for (int kt = 0; kt < nk; ++kt) {
-      if (kt + 1 + pf_dist < nk) touch(kt + 1 + pf_dist);
-      __builtin_amdgcn_s_barrier();
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    return;
-  }
   if (nk > 0) stage(0, 0);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
@@ -677,13 +644,10 @@ int launch_gemm_bf16(const GemmParams& p, hipStream_t st) {
   const char* what = "gemm_bf16_tn";
   if (v[12] == '_') {  // "gemm_bf16_tn_dma"
     what = "gemm_bf16_tn_dma";
-    static const int pf = getenv("DINOX_TN_PREFETCH") ? atoi(getenv("DINOX_TN_PREFETCH")) : 0;      // K-steps of run-ahead (0: off)
-    if (pf > 0 && p.out_dtype == DINOX_F32)
-      hipLaunchKernelGGL((gemm_bf16_tn_dma<DINOX_F32, 1>), grid, dim3(GB_THREADS + 64), lds + 1024, st, q, tiles_m, tiles_n, splits, kps, pf);
-    else if (p.out_dtype == DINOX_F32)
-      hipLaunchKernelGGL((gemm_bf16_tn_dma<DINOX_F32, 0>), grid, dim3(GB_THREADS), lds, st, q, tiles_m, tiles_n, splits, kps, 0);
+    if (p.out_dtype == DINOX_F32)
+      hipLaunchKernelGGL((gemm_bf16_tn_dma<DINOX_F32>), grid, dim3(GB_THREADS), lds, st, q, tiles_m, tiles_n, splits, kps);
     else
-      hipLaunchKernelGGL((gemm_bf16_tn_dma<DINOX_BF16, 0>), grid, dim3(GB_THREADS), lds, st, q, tiles_m, tiles_n, splits, kps, 0);
+      hipLaunchKernelGGL((gemm_bf16_tn_dma<DINOX_BF16>), grid, dim3(GB_THREADS), lds, st, q, tiles_m, tiles_n, splits, kps);
   } else if (p.out_dtype == DINOX_F32) {
     hipLaunchKernelGGL((gemm_bf16_tn<DINOX_F32>), grid, dim3(GB_THREADS), lds, st, q, tiles_m, tiles_n, splits, kps);
   } else {

@@ -409,8 +409,8 @@ static void ar_launch(const GemmParams& p, unsigned ntile, int tiles_n, size_t l
   // ordinary stores for A/B runs.
   // Only for bf16 outputs: the fp32 outputs are the residual stream, which the following LayerNorm reads straight back (neutral on
   // proj here, +9 % on the K = 1536 fc2 product when tried in gemm_bf16_nt_glds, whose bf16 products gain 1-2 %: not adopted there).
-  const char* e = getenv("DINOX_NT_STORES");
-  int nt = e ? atoi(e) : (OUT_DT == DINOX_BF16 ? 1 : 0);
+  static const int knob = getenv("DINOX_NT_STORES") ? atoi(getenv("DINOX_NT_STORES")) : -1;      // read once per process
+  int nt = knob >= 0 ? knob : (OUT_DT == DINOX_BF16 ? 1 : 0);
   // (A/B values: 2 = only outputs of 10 or more column tiles, 3 = only narrower ones.  Whole step on one box: off 44.40 ms, 3: 44.05,
   //  2: 43.34, all bf16 outputs: 43.45.  LayerNorm outputs are the opposite case: stored non-temporally the step LOSES 1.1 ms, the
   //  79 MB they write are still in the last-level cache when the next GEMM reads them.)

@@ -91,8 +91,8 @@ def cpu_baseline(cfg_kw, out_dim, seconds_budget=25.0):
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)      # SURVEY 8d protocol: >= 5 warm-up, >= 20 timed
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch-size", type=int, default=256, help="source samples per GPU")
     ap.add_argument("--fp32", action="store_true", help="parity mode (exact-fp32 MFMA) instead of bf16")
     ap.add_argument("--model", choices=["vit-small", "vit-large"], default="vit-small",
@@ -105,7 +105,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short measurements of the other single-GPU configs")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket GEMM launches with HIP events")
-    ap.add_argument("--time-every", type=int, default=16, help="bracket one GEMM launch in this many with HIP events (1: all; costs ~6 %% of the step)")
+    ap.add_argument("--time-every", type=int, default=16, help="bracket one GEMM launch in this many with HIP events (1: all, which costs the timed region ~2.3 %%)")
     ap.add_argument("--no-step-split", action="store_true", help="skip the extra steps that time the phases of the step (profiler runs)")
     return ap.parse_args(argv)
 

@@ -1552,6 +1552,41 @@ def test_bench_launches_its_own_ranks(dx):
     assert set(d["step_ms_split"]) == {"fwd_student", "fwd_teacher", "loss", "bwd", "comm_exposed", "optimiser_tail"}
 
 
+def test_gemm_timer_samples_launches_and_prices_families(dx):
+    """bench.py's kernel timer (ops.GemmTimer) counts EVERY launch with its algorithmic flops / bytes and brackets one in `every` with HIP
+    events; a family's time is estimated per shape (mean timed duration x launches).  every=1 and every=4 must agree on the counts and, on
+    the same launches, on the time to within launch-to-launch noise; results of the products are untouched by the timer."""
+    ops, _ = dx
+    g = torch.Generator(device="cuda").manual_seed(3)
+    a = (torch.randn(4096, 384, device="cuda", generator=g) * 0.5).bfloat16()
+    w1 = (torch.randn(1536, 384, device="cuda", generator=g) * 0.5).bfloat16()
+    w2 = (torch.randn(384, 1536, device="cuda", generator=g) * 0.5).bfloat16()
+    ref1, ref2 = ops.gemm(a, w1), None
+    ref2 = ops.gemm(ref1, w2)
+    out = {}
+    for every in (1, 4):
+        t = ops.GemmTimer(every=every)
+        ops.GEMM_TIMER = t
+        try:
+            for _ in range(40):
+                h = ops.gemm(a, w1)
+                y = ops.gemm(h, w2)
+        finally:
+            ops.GEMM_TIMER = None
+        torch.cuda.synchronize()
+        assert torch.equal(h, ref1) and torch.equal(y, ref2)
+        out[every] = t.summary()
+    for every, s in out.items():
+        assert sum(d["launches"] for d in s.values()) == 80
+        assert sum(d["flops"] for d in s.values()) == pytest.approx(40 * 2 * (2.0 * 4096 * 384 * 1536))
+        assert all(d["ms"] > 0 and d["bytes"] > 0 for d in s.values())
+    assert sum(d["timed"] for d in out[1].values()) == 80
+    n4 = sum(d["timed"] for d in out[4].values())
+    assert 8 <= n4 <= 36, n4                                     # one in four, by a fixed hash of the launch counter
+    ms1, ms4 = (sum(d["ms"] for d in out[e].values()) for e in (1, 4))
+    assert ms4 == pytest.approx(ms1, rel=0.5)
+
+
 def test_full_size_step_properties(dx):
     """The headline workload itself (ViT-S/16 224, scale-aware, 256 samples = 512 views per step, bf16) -- too big for the CPU oracle, so it
     is held to size-independent properties:

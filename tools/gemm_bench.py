@@ -10,7 +10,16 @@ from dinox import ops
 M = int(os.environ.get("M", 102912))
 dev = "cuda"
 g = torch.Generator(device=dev).manual_seed(0)
-def rb(*s): return (torch.randn(*s, device=dev, generator=g) * 0.5).bfloat16()
+def rb(*s):
+    # DATA=narrow: |x| in [0.125, 0.5) with a random sign (one exponent value, as tools/tile_probe.hip fills its operands);
+    # DATA=gelu: GELU of a unit normal (what fc2 / dW2 see in the step); default: 0.5 * unit normal.  The chip's clocks follow the
+    # operands' toggle rate (MI355X_MICROARCH.md, DVFS), so the same kernel reads differently on each.
+    kind = os.environ.get("DATA", "")
+    if kind == "narrow":
+        return ((torch.rand(*s, device=dev, generator=g) * 0.375 + 0.125) * (torch.randint(0, 2, s, device=dev, generator=g) * 2 - 1)).bfloat16()
+    if kind == "gelu":
+        return torch.nn.functional.gelu(torch.randn(*s, device=dev, generator=g)).bfloat16()
+    return (torch.randn(*s, device=dev, generator=g) * 0.5).bfloat16()
 def rf(*s): return torch.randn(*s, device=dev, generator=g)
 
 cases = {}

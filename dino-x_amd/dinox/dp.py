@@ -110,6 +110,7 @@ class GradBucketer:
         self._seen: set = set()
         self.active = True          # False on all but the last micro-batch of a gradient-accumulation group
         self.fired_in_backward = 0  # buckets of the last step launched from grad_ready (i.e. overlapped), not by finish()
+        self.pre_exchange = lambda: None   # run on the launch stream before a bucket is exchanged (engine: joins the dW stream)
         self._hooks = []
         if self.exchange:
             for i, p in enumerate(params):
@@ -136,12 +137,14 @@ class GradBucketer:
         b.pending -= 1
         if b.pending == 0 and self.exchange and self.active:
             self.fired_in_backward += 1
+            self.pre_exchange()
             b.work = dist.all_reduce(self.flat[b.lo:b.hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def finish(self) -> None:
         """Launch any bucket that never filled (parameters without gradient) and wait for all."""
         if not self.exchange or not self.active:
             return
+        self.pre_exchange()
         for b in self.buckets:
             if b.work is None:
                 b.work = dist.all_reduce(self.flat[b.lo:b.hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)

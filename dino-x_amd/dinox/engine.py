@@ -110,6 +110,7 @@ class TrainEngine:
         dev = self.flat_p.device
         self.center = torch.zeros(1, out_dim, dtype=torch.float32, device=dev)
         self.bucketer = GradBucketer(self.params, self.offsets, self.flat_g, bucket_bytes=bucket_bytes, group=process_group)
+        self.bucketer.pre_exchange = ops.dw_stream.join
         # the teacher forward has no data dependence on the student forward: it runs on its own HIP stream so the two
         # kernel chains fill each other's tails (every launch ends with a partial last round of workgroups)
         self.side_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
@@ -222,6 +223,7 @@ class TrainEngine:
                     t_out = self.teacher.head(t_feats[:, 0])
                 loss, l_dino, l_gram, l_koleo, bm, bm_work = self._losses_and_backward_autograd(s_feats, t_feats, t_out, batch, local_batch,
                                                                                                 local_spacing)
+        ops.dw_stream.join()              # (weight-gradient products enqueued on the dW stream, when DINOX_DW_STREAM is set)
         self._mark("bwd")
         if bm_work is not None:
             bm_work.wait()

@@ -651,14 +651,58 @@ def small_grad(param: Optional[Tensor], g: Optional[Tensor]) -> Optional[Tensor]
     return None
 
 
+class _DwStream:
+    """The weight-gradient products have no consumer inside backward (their results are read by the optimiser, or by a gradient
+    bucket's all-reduce): with DINOX_DW_STREAM=1 they are enqueued on a second HIP stream, so that a dW product (matrix pipe) can
+    share the chip with the memory-bound kernels of the dX chain (LayerNorm backward, attention backward) instead of standing in
+    line between them.  `join()` makes the current stream wait for everything enqueued there (engine: before the optimiser;
+    dp.GradBucketer: before a bucket is exchanged)."""
+
+    def __init__(self) -> None:
+        self.enabled = bool(os.environ.get("DINOX_DW_STREAM"))
+        self.streams: dict = {}
+        self.dirty = False
+
+    def side(self, device):
+        st = self.streams.get(device)
+        if st is None:
+            st = self.streams[device] = torch.cuda.Stream(device=device)
+        return st
+
+    def run(self, fn, *tensors) -> None:
+        main = torch.cuda.current_stream()
+        side = self.side(tensors[0].device)
+        side.wait_stream(main)                     # operands (and the zeroed arena) are products of the main stream
+        with torch.cuda.stream(side):
+            fn()
+        for t in tensors:                          # their memory must outlive the side stream's use of it
+            t.record_stream(side)
+        self.dirty = True
+
+    def join(self) -> None:
+        if self.dirty:
+            main = torch.cuda.current_stream()
+            for st in self.streams.values():
+                main.wait_stream(st)
+            self.dirty = False
+
+
+dw_stream = _DwStream()
+
+
 def weight_grad(dy: Tensor, x: Tensor, w: Tensor, bias: Optional[Tensor], want_db: bool):
     """dW = dy^T x  ([N,M].[M,K]) and, if wanted, db = column sums of dy, from one product.
     Returns (dw, db) for autograd -- or (None, None) after accumulating both into the engine's gradient arena."""
     sw = grad_sink.lookup(w)
     sb = grad_sink.lookup(bias) if want_db else None
     if sw is not None and (not want_db or sb is not None):
-        gemm(dy, x, transA=True, transB=True, out=sw[1].grad.view(w.shape[0], -1), accumulate=True,
-             colsum_out=sb[1].grad if want_db else None)
+        def product():
+            gemm(dy, x, transA=True, transB=True, out=sw[1].grad.view(w.shape[0], -1), accumulate=True,
+                 colsum_out=sb[1].grad if want_db else None)
+        if dw_stream.enabled and dy.is_cuda:
+            dw_stream.run(product, dy, x)
+        else:
+            product()
         grad_sink.ready(sw)
         if want_db:
             grad_sink.ready(sb)
@@ -760,6 +804,8 @@ class BlockFn(torch.autograd.Function):
         b, kw = wt(wqkv)
         dxn1 = gemm(dqkv, b, out_dtype=dt, **kw)
         dwq, dbq = weight_grad(dqkv, xn1.view(M, D), wqkv, bqkv, bqkv is not None)
+        if not bf:
+            dw_stream.join()        # fp32 mode: the proj dW product reads g1 itself (bf16 mode: its own low-precision copy)
         g0, dn1w, dn1b, g0_lp = layernorm_bwd(dxn1, x0, n1w, mean1, rstd1, dx=g1, dx_add=g1, want_lowp=bf, b=n1b)      # in place on our own g1
         g0 = g0.view(V, N, D)
         if g0_lp is not None:

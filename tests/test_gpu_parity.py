@@ -1530,6 +1530,44 @@ def test_training_steps_are_bit_reproducible(dx):
         assert torch.equal(x, y), f"{name}: {int((x != y).sum())} of {x.numel()} elements differ between two identical runs"
 
 
+@pytest.mark.parametrize("amp", [False, True])
+def test_dw_stream_changes_no_bit(dx, amp):
+    """DINOX_DW_STREAM=1 (ops.dw_stream: weight-gradient products enqueued on a second HIP stream, joined before the optimiser / before a
+    bucket is exchanged) must change the ORDER of launches only: three optimiser steps with it end bit-identical to three without, in the
+    fp32 parity mode (where the proj product reads the very buffer LayerNorm's backward then overwrites in place) and in the bf16 mode."""
+    ops, arch = dx
+    from dinox.engine import StepHyperParams, TrainEngine
+    kw = dict(img_size=64, patch=16, dim=384, depth=3, heads=6, num_registers=4, scale_aware=True)
+    torch.manual_seed(5)
+    ref = arch.DinoStudentTeacher(arch.PatchViT(**kw), 1024)
+    torch.nn.init.xavier_uniform_(ref.backbone.scale_embed.mlp[2].weight)
+    sd = {k: v.clone() for k, v in ref.state_dict().items()}
+    g = torch.Generator().manual_seed(6)
+    batches = [(torch.randn(96, 3, 64, 64, generator=g).to(DEV), (torch.rand(48, 3, generator=g) + 0.5).repeat(2, 1).to(DEV)) for _ in range(3)]
+
+    def run(side: bool):
+        was = ops.dw_stream.enabled
+        ops.dw_stream.enabled = side
+        try:
+            student = arch.DinoStudentTeacher(arch.PatchViT(**kw), 1024)
+            teacher = arch.DinoStudentTeacher(arch.PatchViT(**kw), 1024)
+            student.load_state_dict(sd)
+            teacher.load_state_dict(sd)
+            eng = TrainEngine(student.to(DEV), teacher.to(DEV), 1024, StepHyperParams(lr=1e-3, warmup_steps=2, max_steps=8, ema=0.9, koleo_weight=0.1),
+                              amp_dtype=torch.bfloat16 if amp else None, accumulation_steps=1)
+            for b, s in batches:
+                eng.step(b, s)
+            torch.cuda.synchronize()
+            return [t.clone() for t in (eng.flat_p, eng.flat_t, eng.adam_m, eng.adam_v, eng.center, eng.flat_g)]
+        finally:
+            ops.dw_stream.enabled = was
+
+    a, b = run(False), run(True)
+    assert ops.dw_stream.streams, "the side stream was never used"
+    for name, x, y in zip(("student", "teacher", "adam_m", "adam_v", "centre", "last gradient"), a, b):
+        assert torch.equal(x, y), f"{name}: {int((x != y).sum())} of {x.numel()} elements differ with the dW stream"
+
+
 def test_bench_launches_its_own_ranks(dx):
     """`python bench.py --gpus 2` started plainly (no torchrun) spawns its two ranks as child processes itself -- before the parent
     has touched the GPU -- and relays rank 0's line.  Here both ranks share this box's one GPU over gloo (RCCL wants a GPU per

@@ -219,14 +219,20 @@ class PatchViT(nn.Module):
             nn.init.trunc_normal_(self.registers, std=0.02)
 
     def forward(self, x: torch.Tensor, spacing: Optional[torch.Tensor] = None) -> torch.Tensor:
+        g = x.shape[-1] // self.patch
+        if x.shape[-2] != x.shape[-1] or x.shape[-1] % self.patch:
+            raise ValueError(f"input {tuple(x.shape[-2:])} is not a square multiple of the {self.patch}-pixel patch")
+        if x.shape[0] == 0:
+            ops._need_cuda(x, self.pos_embed)
+            # An empty batch launches nothing (the kernels take no null operands).  Like the reference's modules it returns
+            # (0, 1 + P + R, D) in fp32, attached to the parameters so that a backward pass leaves zero gradients, not None.
+            anchor = sum((q.sum() * 0 for q in self.parameters() if q.requires_grad), torch.zeros((), device=x.device))
+            return anchor.expand(0, 1 + g * g + self.num_registers, self.dim) * 1.0
         scale = None
         if self.scale_aware and spacing is not None:
             scale = self.scale_embed(spacing)
         regs = self.registers if self.num_registers > 0 else None
         pos = self.pos_embed
-        g = x.shape[-1] // self.patch
-        if x.shape[-2] != x.shape[-1] or x.shape[-1] % self.patch:
-            raise ValueError(f"input {tuple(x.shape[-2:])} is not a square multiple of the {self.patch}-pixel patch")
         if g * g != pos.shape[1] - 1:       # extension (multi-crop local views): the reference has one input size only
             pos = ops.interp_pos(pos, g)
         t = ops.TokensFn.apply(x, self.patch_embed.weight, self.patch_embed.bias, self.cls_token, pos, regs, scale, self.patch)

@@ -5,6 +5,7 @@ Tolerances: fp32 "parity mode" must meet the north-star gate of 1e-3 relative (w
 tighter where fp32 round-off allows); bf16 "throughput mode" is compared by relative L2 error, since
 bf16 has 2^-9 relative precision per element (the reference's --amp path has the same property).
 """
+import contextlib
 import math
 
 import numpy as np
@@ -1566,6 +1567,24 @@ def test_dw_stream_changes_no_bit(dx, amp):
     assert ops.dw_stream.streams, "the side stream was never used"
     for name, x, y in zip(("student", "teacher", "adam_m", "adam_v", "centre", "last gradient"), a, b):
         assert torch.equal(x, y), f"{name}: {int((x != y).sum())} of {x.numel()} elements differ with the dW stream"
+
+
+def test_empty_batch_is_a_no_op_like_the_reference(dx):
+    """A batch of zero images (the reference's torch modules take it: conv2d / LayerNorm / SDPA of nothing) returns (0, 1 + P + R, D) in
+    fp32 without a launch -- the C ABI takes no null operands -- and a backward pass through it leaves ZERO gradients on every parameter,
+    as autograd does for the reference; a CPU tensor still raises (no CPU fallback)."""
+    ops, arch = dx
+    m = arch.PatchViT(img_size=64, patch=16, dim=384, depth=2, heads=6, num_registers=4, scale_aware=True).to(DEV)
+    for ctx in (contextlib.nullcontext(), torch.autocast("cuda", dtype=torch.bfloat16)):
+        with ctx:
+            y = m(torch.empty(0, 3, 64, 64, device=DEV), spacing=torch.empty(0, 3, device=DEV))
+        assert y.shape == (0, 1 + 16 + 4, 384) and y.dtype == torch.float32 and y.requires_grad
+        m.zero_grad(set_to_none=True)
+        y.sum().backward()
+        for n, q in m.named_parameters():
+            assert q.grad is not None and not q.grad.any(), n
+    with pytest.raises(RuntimeError, match="CPU"):
+        m(torch.empty(0, 3, 64, 64))
 
 
 def test_bench_launches_its_own_ranks(dx):

@@ -72,6 +72,78 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const float* __restr
   }
 }
 
+// Width 384 (ViT-S): a row is 96 float4 = 1.5 wave-loads, so the one-wave-per-row kernel above leaves half the lanes idle in its second
+// load and has one row (1.5 KB) in flight per wave.  Here a HALF wave owns a row (32 lanes x 3 float4, every lane busy, reductions over
+// 32 lanes) and each half walks two rows per iteration, the second requested before the first is reduced: 6 KB in flight per wave.
+template <int OUT_DT>
+__global__ __launch_bounds__(LN_THREADS) void ln_fwd_384(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ b, void* __restrict__ y, float* __restrict__ mean,
+                                                         float* __restrict__ rstd, int64_t rows, float eps) {
+  constexpr int DIM = 384;
+  const int lane = threadIdx.x & 63, sl = lane & 31;
+  const int64_t half = ((int64_t)blockIdx.x * (LN_THREADS / 64) + (threadIdx.x >> 6)) * 2 + (lane >> 5);
+  const int64_t nhalves = (int64_t)gridDim.x * (LN_THREADS / 64) * 2;
+  float4 ww[3], bb[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    ww[j] = reinterpret_cast<const float4*>(w)[sl + 32 * j];
+    bb[j] = reinterpret_cast<const float4*>(b)[sl + 32 * j];
+  }
+  auto sum32 = [](float v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+  };
+  auto finish = [&](const float4 (&v)[3], int64_t r) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    const float mu = sum32(s) * (1.0f / DIM);
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float a = v[j].x - mu, c = v[j].y - mu, d = v[j].z - mu, e = v[j].w - mu;
+      q += (a * a + c * c) + (d * d + e * e);
+    }
+    const float rs = rsqrtf(sum32(q) * (1.0f / DIM) + eps);
+    if (sl == 0) {
+      mean[r] = mu;
+      rstd[r] = rs;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      float4 o;
+      o.x = (v[j].x - mu) * rs * ww[j].x + bb[j].x;
+      o.y = (v[j].y - mu) * rs * ww[j].y + bb[j].y;
+      o.z = (v[j].z - mu) * rs * ww[j].z + bb[j].z;
+      o.w = (v[j].w - mu) * rs * ww[j].w + bb[j].w;
+      if (OUT_DT == DINOX_F32) {
+        reinterpret_cast<float4*>((float*)y + r * DIM)[sl + 32 * j] = o;
+      } else {
+        ushort4 p;
+        p.x = f32_to_bf16(o.x);
+        p.y = f32_to_bf16(o.y);
+        p.z = f32_to_bf16(o.z);
+        p.w = f32_to_bf16(o.w);
+        reinterpret_cast<ushort4*>((bf16_t*)y + r * DIM)[sl + 32 * j] = p;
+      }
+    }
+  };
+  for (int64_t r0 = half; r0 < rows; r0 += 2 * nhalves) {
+    const int64_t r1 = r0 + nhalves;
+    const bool two = r1 < rows;
+    float4 v0[3], v1[3];
+    const float4* x0 = reinterpret_cast<const float4*>(x + r0 * DIM);
+    const float4* x1 = reinterpret_cast<const float4*>(x + (two ? r1 : r0) * DIM);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) v0[j] = x0[sl + 32 * j];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) v1[j] = x1[sl + 32 * j];
+    finish(v0, r0);
+    if (two) finish(v1, r1);
+  }
+}
+
 // Generic (any dim) fallback: one wave per row, three cached passes.
 template <int OUT_DT>
 __global__ __launch_bounds__(LN_THREADS) void ln_fwd_generic(const float* __restrict__ x, const float* __restrict__ w,
@@ -126,8 +198,13 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const void* __restri
   }
   for (int64_t r = wave; r < rows; r += nwaves) {
     const float mu = mean[r], rs = rstd[r];
-    float4 xh[NV], g[NV];
+    float4 xh[NV], g[NV], add[NV];
     float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {      // the incoming residual gradient is requested with the row, not after the two reductions
+      const int c = lane + 64 * j;
+      add[j] = (dx_add && c < nvec) ? reinterpret_cast<const float4*>(dx_add + r * dim)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
       const int c = lane + 64 * j;
@@ -159,10 +236,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const void* __restri
         o.z = rs * (g[j].z - m1 - xh[j].z * m2);
         o.w = rs * (g[j].w - m1 - xh[j].w * m2);
         float4* dst = reinterpret_cast<float4*>(dx + r * dim) + c;
-        if (dx_add) {
-          const float4 p = reinterpret_cast<const float4*>(dx_add + r * dim)[c];
-          o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
-        }
+        o.x += add[j].x; o.y += add[j].y; o.z += add[j].z; o.w += add[j].w;
         *dst = o;
         if (dx_lowp) {
           ushort4 p;
@@ -186,6 +260,105 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const void* __restri
   float* out = ws + (size_t)blockIdx.x * 2 * dim;
   for (int c = threadIdx.x; c < 2 * dim; c += LN_THREADS)
     out[c] = (lds[c] + lds[2 * dim + c]) + (lds[4 * dim + c] + lds[6 * dim + c]);
+}
+
+// Width 384, backward: the same half-wave-per-row form as ln_fwd_384 (every lane busy, two rows requested per half before the first
+// is reduced, the incoming residual gradient dx_add fetched with them instead of after the reductions).  dx may alias dx_add: a row is
+// read and written by the same lanes, each element read before it is written.  The per-column partial sums of a half wave meet its
+// twin (lane ^ 32 holds the same columns) by one exchange, then the block's four waves through LDS as in ln_bwd_kernel.
+template <int DY_DT>
+__global__ __launch_bounds__(LN_THREADS) void ln_bwd_384(const void* __restrict__ dy, const float* __restrict__ x,
+                                                         const float* __restrict__ w, const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd, float* dx, void* __restrict__ dx_lowp,
+                                                         float* __restrict__ ws, int64_t rows, const float* dx_add) {
+  constexpr int DIM = 384;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63, sl = lane & 31, wv = threadIdx.x >> 6;
+  const int64_t half = ((int64_t)blockIdx.x * (LN_THREADS / 64) + wv) * 2 + (lane >> 5);
+  const int64_t nhalves = (int64_t)gridDim.x * (LN_THREADS / 64) * 2;
+  float4 aw[3], ab[3], wreg[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    aw[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    ab[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    wreg[j] = reinterpret_cast<const float4*>(w)[sl + 32 * j];
+  }
+  auto sum32 = [](float v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+  };
+  auto fetch = [&](int64_t r, float4 (&xv)[3], float4 (&d)[3], float4 (&a)[3]) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int c = sl + 32 * j;
+      xv[j] = reinterpret_cast<const float4*>(x + r * DIM)[c];
+      if (DY_DT == DINOX_F32) {
+        d[j] = reinterpret_cast<const float4*>((const float*)dy + r * DIM)[c];
+      } else {
+        const ushort4 p = reinterpret_cast<const ushort4*>((const bf16_t*)dy + r * DIM)[c];
+        d[j] = make_float4(bf16_to_f32(p.x), bf16_to_f32(p.y), bf16_to_f32(p.z), bf16_to_f32(p.w));
+      }
+      a[j] = dx_add ? reinterpret_cast<const float4*>(dx_add + r * DIM)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto finish = [&](int64_t r, const float4 (&xv)[3], const float4 (&d)[3], const float4 (&a)[3]) {
+    const float mu = mean[r], rs = rstd[r];
+    float4 xh[3], g[3];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      xh[j] = make_float4((xv[j].x - mu) * rs, (xv[j].y - mu) * rs, (xv[j].z - mu) * rs, (xv[j].w - mu) * rs);
+      g[j] = make_float4(d[j].x * wreg[j].x, d[j].y * wreg[j].y, d[j].z * wreg[j].z, d[j].w * wreg[j].w);
+      aw[j].x += d[j].x * xh[j].x; aw[j].y += d[j].y * xh[j].y; aw[j].z += d[j].z * xh[j].z; aw[j].w += d[j].w * xh[j].w;
+      ab[j].x += d[j].x; ab[j].y += d[j].y; ab[j].z += d[j].z; ab[j].w += d[j].w;
+      s1 += (g[j].x + g[j].y) + (g[j].z + g[j].w);
+      s2 += (g[j].x * xh[j].x + g[j].y * xh[j].y) + (g[j].z * xh[j].z + g[j].w * xh[j].w);
+    }
+    const float m1 = sum32(s1) * (1.0f / DIM), m2 = sum32(s2) * (1.0f / DIM);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int c = sl + 32 * j;
+      float4 o;
+      o.x = rs * (g[j].x - m1 - xh[j].x * m2) + a[j].x;
+      o.y = rs * (g[j].y - m1 - xh[j].y * m2) + a[j].y;
+      o.z = rs * (g[j].z - m1 - xh[j].z * m2) + a[j].z;
+      o.w = rs * (g[j].w - m1 - xh[j].w * m2) + a[j].w;
+      reinterpret_cast<float4*>(dx + r * DIM)[c] = o;
+      if (dx_lowp) {
+        ushort4 p;
+        p.x = f32_to_bf16(o.x); p.y = f32_to_bf16(o.y); p.z = f32_to_bf16(o.z); p.w = f32_to_bf16(o.w);
+        reinterpret_cast<ushort4*>((bf16_t*)dx_lowp + r * DIM)[c] = p;
+      }
+    }
+  };
+  for (int64_t r0 = half; r0 < rows; r0 += 2 * nhalves) {
+    const int64_t r1 = r0 + nhalves;
+    const bool two = r1 < rows;
+    float4 x0[3], d0[3], a0[3], x1[3], d1[3], a1[3];
+    fetch(r0, x0, d0, a0);
+    fetch(two ? r1 : r0, x1, d1, a1);
+    finish(r0, x0, d0, a0);
+    if (two) finish(r1, x1, d1, a1);
+  }
+  // the twin half (same columns), then the block's four waves: lds[wv][2][DIM]
+  float* mine = lds + (size_t)wv * 2 * DIM;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    float4 sw, sb;
+    sw.x = aw[j].x + __shfl_xor(aw[j].x, 32, 64); sw.y = aw[j].y + __shfl_xor(aw[j].y, 32, 64);
+    sw.z = aw[j].z + __shfl_xor(aw[j].z, 32, 64); sw.w = aw[j].w + __shfl_xor(aw[j].w, 32, 64);
+    sb.x = ab[j].x + __shfl_xor(ab[j].x, 32, 64); sb.y = ab[j].y + __shfl_xor(ab[j].y, 32, 64);
+    sb.z = ab[j].z + __shfl_xor(ab[j].z, 32, 64); sb.w = ab[j].w + __shfl_xor(ab[j].w, 32, 64);
+    if (lane < 32) {
+      reinterpret_cast<float4*>(mine)[sl + 32 * j] = sw;
+      reinterpret_cast<float4*>(mine + DIM)[sl + 32 * j] = sb;
+    }
+  }
+  __syncthreads();
+  float* out = ws + (size_t)blockIdx.x * 2 * DIM;
+  for (int c = threadIdx.x; c < 2 * DIM; c += LN_THREADS)
+    out[c] = (lds[c] + lds[2 * DIM + c]) + (lds[4 * DIM + c] + lds[6 * DIM + c]);
 }
 
 template <int DY_DT>
@@ -266,6 +439,16 @@ extern "C" int dinox_layernorm_fwd(const float* x, const float* w, const float* 
   if (blocks > 256 * 16) blocks = 256 * 16;
   hipStream_t st = as_stream(stream);
   const bool fast = (dim % 4 == 0) && dim <= 256 * LN_MAXV;
+  static const bool no384 = getenv("DINOX_LN_NO384") != nullptr;                     // A/B knob
+  if (dim == 384 && !no384 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)w | (uintptr_t)b) & 15) == 0) {
+    int64_t blk = ceil_div(rows, (int64_t)(LN_THREADS / 64) * 2 * 2);             // two rows per half wave and iteration
+    if (blk > 256 * 8) blk = 256 * 8;
+    if (out_dtype == DINOX_F32)
+      hipLaunchKernelGGL((ln_fwd_384<DINOX_F32>), dim3((unsigned)blk), dim3(LN_THREADS), 0, st, x, w, b, y, mean, rstd, rows, eps);
+    else
+      hipLaunchKernelGGL((ln_fwd_384<DINOX_BF16>), dim3((unsigned)blk), dim3(LN_THREADS), 0, st, x, w, b, y, mean, rstd, rows, eps);
+    return check_launch("layernorm_fwd");
+  }
 #define LN_FWD(DT, NV) hipLaunchKernelGGL((ln_fwd_kernel<DT, NV>), dim3((unsigned)blocks), dim3(LN_THREADS), 0, st, x, w, b, y, mean, rstd, rows, dim, eps)
   if (fast) {
     const int nv = (int)ceil_div(dim / 4, 64);
@@ -300,6 +483,20 @@ extern "C" int dinox_layernorm_bwd(const void* dy, const float* x, const float* 
   const size_t lds = (size_t)(LN_THREADS / 64) * 2 * dim * sizeof(float);
   const bool fast = (dim % 4 == 0) && dim <= 256 * LN_MAXV && lds <= 64 * 1024;
   float* wsf = (float*)ws;
+  static const bool no384 = getenv("DINOX_LN_NO384") != nullptr;                     // A/B knob
+  const bool al16 = (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)dx_add | (uintptr_t)dx_lowp | (uintptr_t)w) & 15) == 0;
+  if (dim == 384 && !no384 && al16) {
+    // 167 registers = three waves per SIMD = three blocks per CU: 768 blocks are one resident round (the workspace holds `parts` >= that)
+    const int64_t want = ceil_div(rows, (int64_t)(LN_THREADS / 64) * 2 * 2);
+    const int nblk = (int)(want < parts ? want : (parts < 768 ? parts : 768));
+    if (dy_dtype == DINOX_F32)
+      hipLaunchKernelGGL((ln_bwd_384<DINOX_F32>), dim3(nblk), dim3(LN_THREADS), lds, st, dy, x, w, mean, rstd, dx, dx_lowp, wsf, rows, dx_add);
+    else
+      hipLaunchKernelGGL((ln_bwd_384<DINOX_BF16>), dim3(nblk), dim3(LN_THREADS), lds, st, dy, x, w, mean, rstd, dx, dx_lowp, wsf, rows, dx_add);
+    if (int rc = check_launch("layernorm_bwd")) return rc;
+    hipLaunchKernelGGL(ln_bwd_reduce, dim3((unsigned)ceil_div(2 * dim, 4)), dim3(256), 0, st, wsf, dw, db, nblk, dim, accumulate ? 1 : 0);
+    return check_launch("layernorm_bwd_reduce");
+  }
 #define LN_BWD(DT, NV) hipLaunchKernelGGL((ln_bwd_kernel<DT, NV>), dim3(parts), dim3(LN_THREADS), lds, st, dy, x, w, mean, rstd, dx, dx_lowp, wsf, rows, dim, dx_add)
   if (fast) {
     const int nv = (int)ceil_div(dim / 4, 64);

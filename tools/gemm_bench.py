@@ -45,6 +45,8 @@ gam, bet = rf(D), rf(D)
 case("projLN rowln K384 +res +LN->bf16 ", lambda: ops.linear_residual_ln(x, wproj, bd, res, gam, bet, 1e-5, torch.bfloat16), 2 * M * D * D, M * D * 2 + 2 * M * D * 4 + M * D * 2)
 case("fc2LN  rowln K1536 +res +LN->bf16", lambda: ops.linear_residual_ln(xh, w2, bd, res, gam, bet, 1e-5, torch.bfloat16), 2 * M * D * H, M * H * 2 + 2 * M * D * 4 + M * D * 2)
 case("ln_fwd 384 fp32 -> bf16          ", lambda: ops.layernorm_fwd(res, gam, bet, torch.bfloat16), 8 * M * D, M * D * 4 + M * D * 2)
+_y, _mean, _rstd = ops.layernorm_fwd(res, gam, bet, torch.bfloat16)
+case("ln_bwd 384 bf16 dy +dx_add +lowp   ", lambda: ops.layernorm_bwd(x, res, gam, _mean, _rstd, dx_add=res, want_lowp=True), 16 * M * D, M * D * (2 + 4 + 4 + 4 + 2))
 db = torch.empty(H, device=dev)
 case("dW1   TN M1536 N384  (+db)       ", lambda: ops.gemm(xh, x, transA=True, transB=True, out_dtype=torch.float32, colsum_out=db), 2 * M * D * H, M * H * 2 + M * D * 2)
 dbq = torch.empty(3 * D, device=dev)

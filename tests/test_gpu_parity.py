@@ -1289,10 +1289,16 @@ def test_reference_written_checkpoint_resumes_in_engine(dx):
     assert got["grad_norm"] == pytest.approx(float(g["grad_norms"][3]), rel=1e-3)
     assert got["lr"] == pytest.approx(float(g["lrs"][3]), rel=1e-12)
     assert eng.opt_steps == int(g["adam_step4"])
-    for k, v in sub(g, "student4").items():
-        close(student.state_dict()[k], v, 1e-3, 2e-5, f"student after step 4: {k}")
-    for k, v in sub(g, "teacher4").items():
-        close(teacher.state_dict()[k], v, 1e-3, 2e-5, f"teacher after step 4: {k}")
+    def close_params(model, want, what):
+        for k, v in want.items():
+            got_k = model.state_dict()[k]
+            if k.endswith("attn.qkv.bias"):      # key part: numerically-zero gradient, Adam moves it by up to lr with a round-off sign
+                D = v.numel() // 3               # (same rule as the payload test below) -> one step x lr
+                close(got_k[D:2 * D], v[D:2 * D], 0, 1.1e-3, f"{what}: {k} (key part)")
+                got_k, v = torch.cat([got_k[:D], got_k[2 * D:]]), torch.cat([v[:D], v[2 * D:]])
+            close(got_k, v, 1e-3, 2e-5, f"{what}: {k}")
+    close_params(student, sub(g, "student4"), "student after step 4")
+    close_params(teacher, sub(g, "teacher4"), "teacher after step 4")
     close(eng.center, g["center4"], 1e-4, 1e-7, "centre after step 4")
 
 

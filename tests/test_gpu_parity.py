@@ -173,8 +173,9 @@ def test_colsum(dx):
 
 
 # ------------------------------------------------------------------------------------------ LayerNorm
-@pytest.mark.parametrize("rows,dim", [(7, 64), (804, 384), (33, 1024), (5, 50)])
-def test_layernorm(dx, rows, dim):
+@pytest.mark.parametrize("rows,dim", [(7, 64), (804, 384), (33, 1024), (5, 50),
+                                      (1, 384), (3, 384), (4099, 384), (33001, 384)])   # width 384 has its own kernels (half a wave per row,
+def test_layernorm(dx, rows, dim):                                                        # two rows per half and sweep): ragged row counts
     ops, _ = dx
     from oracle import kernels_np as K
     rng = np.random.default_rng(rows + dim)

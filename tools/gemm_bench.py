@@ -38,6 +38,8 @@ case("proj  NT K384 N384  bias+res f32", lambda: ops.gemm(x, wproj, bias=bd, res
 case("fc1   NT K384 N1536 bias+gelu+aux", lambda: ops.gemm(x, w1, bias=bh, gelu=True, aux=pre, auxgrad=True), 2 * M * D * H, M * D * 2 + 2 * M * H * 2)
 case("fc1t  NT K384 N1536 bias+gelu    ", lambda: ops.gemm(x, w1, bias=bh, gelu=True), 2 * M * D * H, M * D * 2 + M * H * 2)
 case("fc2   NT K1536 N384 bias+res f32", lambda: ops.gemm(xh, w2, bias=bd, residual=res, out_dtype=torch.float32), 2 * M * D * H, M * H * 2 + 2 * M * D * 4)
+case("fc2p  NT K1536 N384 plain f32 out ", lambda: ops.gemm(xh, w2, out_dtype=torch.float32), 2 * M * D * H, M * H * 2 + M * D * 4)
+case("fc2b  NT K1536 N384 bias f32 out  ", lambda: ops.gemm(xh, w2, bias=bd, out_dtype=torch.float32), 2 * M * D * H, M * H * 2 + M * D * 4)
 case("dact  NT K384 N1536 dgelu        ", lambda: ops.gemm(x, w2T, dgelu=True, aux=pre, auxgrad=True), 2 * M * D * H, M * D * 2 + 2 * M * H * 2)
 case("dxn2  NT K1536 N384 plain        ", lambda: ops.gemm(xh, w1T), 2 * M * D * H, M * H * 2 + M * D * 2)
 case("dxn1  NT K1152 N384 plain        ", lambda: ops.gemm(x3, wqkvT), 2 * M * D * 3 * D, M * 3 * D * 2 + M * D * 2)

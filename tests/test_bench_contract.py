@@ -46,5 +46,10 @@ def test_recorded_bench_line_meets_the_contract():
         for k, v in sec.items():
             assert "error" not in v, (k, v)
             assert v["unit"] == "samples/s" and v["value"] > 0 and v["ms_per_step"] > 0 and v["workload"]
+    if "framework_baseline" in d:                   # the same oracle step through plain PyTorch-ROCm on the same GPU (round 2 on)
+        f = d["framework_baseline"]
+        assert "error" not in f, f
+        assert f["unit"] == d["unit"] and f["kind"] == "port" and f["value"] > 0 and f["sample"]
+        assert f["speedup"] == pytest.approx(d["value"] / f["value"], rel=1e-2)
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]

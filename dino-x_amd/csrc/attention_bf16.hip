@@ -886,6 +886,12 @@ __global__ __launch_bounds__(448) void attn_bwd_fused_bf16(const bf16_t* __restr
 }
 
 // ------------------------------------------------------------------------------------------ launchers
+// Workgroups of a persistent attention kernel that fit one CU: 160 KiB of LDS, and 8 waves (the kernels sit at ~250 registers: two per SIMD).
+static int persist_wgs_per_cu(size_t lds_bytes, int waves) {
+  const int by_lds = (int)((size_t)160 * 1024 / (lds_bytes ? lds_bytes : 1)), by_waves = 8 / (waves > 0 ? waves : 1);
+  const int n = by_lds < by_waves ? by_lds : by_waves;
+  return n < 1 ? 1 : n;
+}
 static void geometry(int N, int& nblk, int& nwg, int& waves) {
   nblk = (N + 31) / 32;
   nwg = (nblk + 7) / 8;
@@ -904,11 +910,14 @@ int launch_attention_bf16_fwd(const void* qkv, void* o, float* lse, int B, int N
   const float sc = 1.0f / sqrtf((float)d);
   {
     const int nw = nblk < 8 ? nblk : 8;
-    const size_t lds = (size_t)4 * nblk * 32 * 128 + 8 * 32 * sizeof(float) + 8 * (size_t)ST_BYTES;     // images, 1/rowsum, output staging
+    const size_t lds = (size_t)4 * nblk * 32 * 128 + 8 * 32 * sizeof(float) + (size_t)nw * ST_BYTES;    // images, 1/rowsum, output staging (per wave)
     static const bool off = getenv("DINOX_ATTN_NO_PERSIST") != nullptr;
     if (lds <= 160 * 1024 && !off && nblk <= nw) {          // one query block per wave (the kernel relies on it)
       const int npairs = B * heads;
-      const int nwgp = npairs < 256 ? npairs : 256;                 // one resident workgroup per CU
+      // resident workgroups: one per CU at 7 blocks (201 tokens); short sequences (the 41-token local crops: two waves, 41 KiB) get as many as
+      // LDS and two waves per SIMD allow -- with one the chip ran half a wave per SIMD (113 us for 5 GFLOP at N = 41)
+      const int per_cu = persist_wgs_per_cu(lds, nw);
+      const int nwgp = npairs < 256 * per_cu ? npairs : 256 * per_cu;
 #define PFWD(NKT)                                                                                                                  \
   do {                                                                                                                             \
     if (int rc = allow_lds(attn_fwd_bf16_persist<NKT>, lds)) return fail(rc, "attention_fwd: cannot reserve %zu B of LDS", lds);   \
@@ -945,7 +954,8 @@ int launch_attention_bf16_bwd(const void* d_o, const void* qkv, const void* o, c
     static const bool split = getenv("DINOX_ATTN_BWD_SPLIT") != nullptr;
     if (nblk <= 7 && ldsf <= 160 * 1024 && !split) {
       const int npairs = B * heads;
-      const int nwgp = npairs < 256 ? npairs : 256;
+      const int per_cu = persist_wgs_per_cu(ldsf, nblk);
+      const int nwgp = npairs < 256 * per_cu ? npairs : 256 * per_cu;
       if (int rc = allow_lds(attn_bwd_fused_bf16, ldsf)) return fail(rc, "attention_bwd: cannot reserve %zu B of LDS", ldsf);
       hipLaunchKernelGGL(attn_bwd_fused_bf16, dim3(nwgp), dim3(nblk * 64), ldsf, st, (const bf16_t*)d_o, (const bf16_t*)qkv, (const bf16_t*)o, lse,
                          (bf16_t*)dqkv, N, heads, nblk, sc, npairs);

@@ -350,7 +350,15 @@ int launch_gemm_bf16_nt_glds(const GemmParams& p, hipStream_t st) {
   static const int knob = getenv("DINOX_NT_BK") ? atoi(getenv("DINOX_NT_BK")) : 0;   // tuning knobs (A/B testing)
   static const int knob_bm = getenv("DINOX_NT_BM") ? atoi(getenv("DINOX_NT_BM")) : 0;
   // measured (tools/gemm_bench.py): K <= 512 runs faster on the 3-stage BK=32 ring, longer K on the 2-stage BK=64 form
-  const int bk = knob ? knob : (p.K <= 512 ? 32 : 64);
+  // ... unless the tile count fills the 512 resident slots of the BK = 64 form so badly (bs 64: fc2 / dX are 603 tiles = 1.18 rounds) that the 768 slots
+  // of the BK = 32 form win although it is ~10 % slower per tile (measured at bs 256: fc2 233 vs 210 us, dX 195 vs 175 us)
+  int bk_auto = p.K <= 512 ? 32 : 64;
+  if (bk_auto == 64) {
+    const int64_t nt = ceil_div(p.M, (int64_t)128) * ceil_div(p.N, (int64_t)GG_BN) * p.batch;
+    const double e512 = (double)nt / (double)(ceil_div(nt, (int64_t)512) * 512), e768 = (double)nt / (double)(ceil_div(nt, (int64_t)768) * 768);
+    if (0.9 * e768 > e512) bk_auto = 32;
+  }
+  const int bk = knob ? knob : bk_auto;
   // the 256-row tile (128x64 per wave) measures within +-5 % of the 128-row tile on every hot-path shape (tools/gemm_bench.py),
   // so the smaller one (more workgroups per CU, finer tail) stays the default; DINOX_NT_BM=256 selects the other
   const int bm = knob_bm ? knob_bm : 128;

@@ -170,7 +170,8 @@ def launch_ranks(args) -> int:
 class Workload:
     """One configuration resident on the device: models, engine, synthetic batch."""
 
-    def __init__(self, dev, rank, *, model="vit-small", B=256, scale_aware=True, L=0, local_size=96, fp32=False, steps_hint=30, graph=False):
+    def __init__(self, dev, rank, *, model="vit-small", B=256, scale_aware=True, L=0, local_size=96, fp32=False, steps_hint=30, graph=False, koleo=0.0,
+                 accum=1):
         import torch
         import zoo.arch as arch
         from dinox.engine import StepHyperParams, TrainEngine
@@ -184,8 +185,8 @@ class Workload:
             torch.nn.init.xavier_uniform_(student.backbone.scale_embed.mlp[2].weight)
         teacher = arch.DinoStudentTeacher(arch.PatchViT(**self.cfg_kw), self.out_dim)
         teacher.load_state_dict(student.state_dict())
-        self.eng = TrainEngine(student.to(dev), teacher.to(dev), self.out_dim, StepHyperParams(max_steps=steps_hint + 10, warmup_steps=5),
-                               amp_dtype=None if fp32 else torch.bfloat16, **({"use_graph": True} if graph else {}))
+        self.eng = TrainEngine(student.to(dev), teacher.to(dev), self.out_dim, StepHyperParams(max_steps=steps_hint + 10, warmup_steps=5, koleo_weight=koleo),
+                               amp_dtype=None if fp32 else torch.bfloat16, accumulation_steps=accum, **({"use_graph": True} if graph else {}))
         g = torch.Generator().manual_seed(1234 + rank)       # per-rank shard of the synthetic global batch
         self.batch = torch.randn(2 * B, 3, 224, 224, generator=g).to(dev)
         sp = (torch.rand(B, 3, generator=g) * torch.tensor([0.52, 0.52, 4.375]) + torch.tensor([0.46, 0.46, 0.625]))
@@ -250,6 +251,8 @@ def secondary(dev, note) -> dict:
     from dinox import ops
     runs = [("bs256_dw_stream", dict(B=256, dw_stream=True),
              "the headline workload with DINOX_DW_STREAM=1 (weight-gradient products on a second HIP stream: faster, but overlapping kernels cannot be priced one by one, so the headline line keeps it off)"),
+            ("bs256_koleo_accum4", dict(B=256, koleo=0.1, accum=4),
+             "the headline workload the way the reference's production runs use it (docs/EXPERIMENTS.md): --koleo-weight 0.1, --accumulation-steps 4 (samples/s counts micro-batches)"),
             ("bs64_scale_off", dict(B=64, scale_aware=False), "BASELINE configs[1]: ViT-S/16 224, bs 64, scale-aware off, 2 views/sample"),
             ("bs64_scale_off_graph", dict(B=64, scale_aware=False, graph=True), "configs[1] with the step replayed as one captured hipGraph"),
             ("multicrop_2g8l", dict(B=256, L=8), "configs[2] read literally: 2 global + 8 local 96px views/sample (extension: the reference has 2 views)"),

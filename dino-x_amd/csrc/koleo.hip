@@ -173,6 +173,22 @@ extern "C" int dinox_koleo_nn(const float* G, int64_t ldg, const float* sq_all, 
   return check_launch("koleo_nn");
 }
 
+// loss = -mean_i log(dist_i + eps) over this rank's rows: one block, fixed order
+__global__ __launch_bounds__(256) void koleo_loss_kernel(const float* __restrict__ dist, int V, float eps, float* __restrict__ out) {
+  __shared__ float red[16];
+  float a = 0.f;
+  for (int i = threadIdx.x; i < V; i += 256) a += logf(dist[i] + eps);
+  a = dinox::block_sum(a, red);
+  if (threadIdx.x == 0) out[0] = -a / (float)V;
+}
+
+extern "C" int dinox_koleo_loss(const float* dist, int V, float eps, float* loss, void* stream) {
+  DX_REQUIRE(dist && loss, DINOX_EINVAL, "koleo_loss: null pointer");
+  DX_REQUIRE(V > 0, DINOX_EINVAL, "koleo_loss: V=%d", V);
+  hipLaunchKernelGGL(koleo_loss_kernel, dim3(1), dim3(256), 0, as_stream(stream), dist, V, eps, loss);
+  return check_launch("koleo_loss");
+}
+
 extern "C" int dinox_koleo_bwd(const float* xh_all, const int* idx_all, const float* dist_all, const float* norm_loc, int row0, int V_l,
                                int V_g, int D, float gscale, float eps, float norm_eps, float* dx, void* stream) {
   DX_REQUIRE(xh_all && idx_all && dist_all && norm_loc && dx, DINOX_EINVAL, "koleo_bwd: null pointer");

@@ -69,6 +69,7 @@ SIGNATURES = {
     "dinox_slice_views": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
     "dinox_koleo_normalize": (i32, [vp, vp, vp, vp, i64, i32, f32, vp]),
     "dinox_koleo_nn": (i32, [vp, i64, vp, vp, i32, i32, i32, i32, vp, vp, vp]),
+    "dinox_koleo_loss": (i32, [vp, i32, f32, vp, vp]),
     "dinox_koleo_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, f32, vp, vp]),
     "dinox_adamw_ema": (i32, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, f32, vp, vp, vp]),
     "dinox_adamw_ema_dev": (i32, [vp, vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, f32, f32, vp, vp, vp]),

@@ -311,15 +311,8 @@ class TrainEngine:
             bm_work = dist.all_reduce(bm, op=dist.ReduceOp.SUM, group=self.group, async_op=True) if exchanging(self.group) else None
             l_koleo = None
             if hp.koleo_weight > 0.0:                        # :1764-1766; nearest neighbours over the global batch under DP
-                with torch.enable_grad():
-                    xk = s_all[:V].detach().requires_grad_(True)
-                    l_koleo = ops.koleo_loss(xk, group=self.group)
-                    l_koleo.backward()
-                if local_batch is None:
-                    ops.axpy_(ds, xk.grad, hp.koleo_weight * scale)
-                else:
-                    ds[:V].add_(xk.grad, alpha=hp.koleo_weight * scale)
-                l_koleo = l_koleo.detach().reshape(1)
+                l_koleo, ksaved = ops.koleo_fwd(s_all[:V], group=self.group)
+                ops.axpy_(ds[:V], ops.koleo_bwd(ksaved, hp.koleo_weight * scale), 1.0)      # (ds[:V]: the leading rows, contiguous)
             dcls = self._head_backward(self.student.head, saved, ds)
             dfeats = torch.empty_like(sf)
             l_gram = None

@@ -246,6 +246,33 @@ def _tn_workspace(nbytes: int, device) -> Tensor:
     return ws
 
 
+def gemm_nt_f32_splitk(A: Tensor, B: Tensor, splits: int = 0) -> Tensor:
+    """A [M,K] . B [N,K]^T in exact fp32 with the reduction cut into K-chunks that run as ONE batched launch (operand strides: chunk c
+    starts K/splits elements further along every row) and meet in a fixed-order column sum.  For few-tile, long-K products: the KoLeo
+    inner products are 512 x 512 x 8192 = 16 tiles, i.e. 16 workgroups on 256 CUs and 784 us as a plain product."""
+    _need_cuda(A, B)
+    assert A.dtype == torch.float32 and B.dtype == torch.float32 and A.is_contiguous() and B.is_contiguous() and A.dim() == 2 and B.dim() == 2
+    M, K = A.shape
+    N = B.shape[0]
+    assert B.shape[1] == K
+    if splits <= 0:
+        tiles = ((M + 127) // 128) * ((N + 127) // 128)
+        splits = max(1, min(K // 256, 256 // max(tiles, 1)))
+    while splits > 1 and K % splits:
+        splits -= 1
+    if splits == 1:
+        return gemm(A, B, out_dtype=torch.float32)
+    kc = K // splits
+    part = torch.empty((splits, M, N), dtype=torch.float32, device=A.device)
+    g = GemmArgs(A=_p(A), B=_p(B), C=_p(part), M=M, N=N, K=kc, lda=K, ldb=K, ldc=N, batch=splits, strideA=kc, strideB=kc, strideC=M * N,
+                 transA=0, transB=0, in_dtype=F32, out_dtype=F32, epilogue=0, alpha=1.0, bias=None, residual=None, ldr=N, aux=None, ldaux=N,
+                 colsum=None, ws=None)
+    if TRACE_KERNELS is not None:
+        TRACE_KERNELS.append(lib.dinox_gemm_kernel_name(C.byref(g)).decode())
+    check(lib.dinox_gemm(C.byref(g), _stream()), "dinox_gemm")
+    return colsum(part.view(splits, M * N)).view(M, N)
+
+
 def colsum(x: Tensor, out: Optional[Tensor] = None, accumulate=False) -> Tensor:
     x2 = _c(x).reshape(-1, x.shape[-1])
     if out is None:
@@ -1281,61 +1308,72 @@ class GramLossFn(torch.autograd.Function):
         return d * g, None
 
 
-class KoLeoFn(torch.autograd.Function):
+def koleo_fwd(x: Tensor, eps: float = 1e-8, group=None):
     """KoLeo regulariser on the student head output (reference scripts/phase5_big_run.py:742-773, applied at :1764-1766):
     -mean_i log(min_{j != i} ||x^_i - x^_j|| + eps) with x^ = F.normalize(x).  fp32 in both modes, like cdist under autocast.
+    Returns (loss[1], saved) -- no autograd, no framework kernel; koleo_bwd(saved, gscale) gives d(gscale * loss)/dx.
 
     Data parallel (``group`` with more than one rank): the neighbour of a row is searched over the GLOBAL batch, as the
     single-process reference would at that batch size.  Two all-gathers (unit rows; then index + distance per row) and no
     gradient collective: a row's gradient needs its own pair and the pairs that chose it, all of which are gathered data.
     The value returned is this rank's mean over its own rows, so the mean over ranks is the global loss."""
+    import torch.distributed as dist
+    _need_cuda(x)
+    x = _c(x.float())
+    V, D = x.shape
+    dev = x.device
+    from .dp import exchanging
+    gather = exchanging(group)
+    world = dist.get_world_size(group) if gather else 1
+    rank = dist.get_rank(group) if gather else 0
+    f = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
+    xh, norm, sq = f(V, D), f(V), f(V)
+    check(lib.dinox_koleo_normalize(_p(x), _p(xh), _p(norm), _p(sq), V, D, 1e-12, _stream()), "dinox_koleo_normalize")
+    if gather:
+        xh_all, sq_all = f(world * V, D), f(world * V)
+        dist.all_gather_into_tensor(xh_all, xh, group=group)
+        dist.all_gather_into_tensor(sq_all, sq, group=group)
+    else:
+        xh_all, sq_all = xh, sq
+    Vg, row0 = world * V, rank * V
+    G = gemm_nt_f32_splitk(xh, xh_all)                                  # [V, Vg] inner products, exact-fp32 MFMA, reduction split over the chip
+    idx = torch.empty(V, dtype=torch.int32, device=dev)
+    dmin = f(V)
+    check(lib.dinox_koleo_nn(_p(G), Vg, _p(sq_all), _p(xh_all), row0, V, Vg, D, _p(idx), _p(dmin), _stream()), "dinox_koleo_nn")
+    if gather:
+        idx_all = torch.empty(Vg, dtype=torch.int32, device=dev)
+        d_all = f(Vg)
+        dist.all_gather_into_tensor(idx_all, idx, group=group)
+        dist.all_gather_into_tensor(d_all, dmin, group=group)
+    else:
+        idx_all, d_all = idx, dmin
+    loss = f(1)
+    check(lib.dinox_koleo_loss(_p(dmin), V, eps, _p(loss), _stream()), "dinox_koleo_loss")
+    return loss, (xh_all, idx_all, d_all, norm, (row0, V, Vg, D), eps)
+
+
+def koleo_bwd(saved, gscale: float = 1.0) -> Tensor:
+    """dx [V, D] = d(gscale * koleo loss) / dx (the upstream factor is a host scalar here: loss weight / accumulation steps)."""
+    xh_all, idx_all, d_all, norm, (row0, V, Vg, D), eps = saved
+    dx = torch.empty((V, D), dtype=torch.float32, device=xh_all.device)
+    check(lib.dinox_koleo_bwd(_p(xh_all), _p(idx_all), _p(d_all), _p(norm), row0, V, Vg, D, gscale / V, eps, 1e-12, _p(dx), _stream()),
+          "dinox_koleo_bwd")
+    return dx
+
+
+class KoLeoFn(torch.autograd.Function):
+    """koleo_fwd / koleo_bwd as an autograd node (the engine's fallback path and callers outside the engine)."""
 
     @staticmethod
     def forward(ctx, x, eps, group):
-        import torch.distributed as dist
-        _need_cuda(x)
-        x = _c(x.float())
-        V, D = x.shape
-        dev = x.device
-        from .dp import exchanging
-        gather = exchanging(group)
-        world = dist.get_world_size(group) if gather else 1
-        rank = dist.get_rank(group) if gather else 0
-        f = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
-        xh, norm, sq = f(V, D), f(V), f(V)
-        check(lib.dinox_koleo_normalize(_p(x), _p(xh), _p(norm), _p(sq), V, D, 1e-12, _stream()), "dinox_koleo_normalize")
-        if gather:
-            xh_all, sq_all = f(world * V, D), f(world * V)
-            dist.all_gather_into_tensor(xh_all, xh, group=group)
-            dist.all_gather_into_tensor(sq_all, sq, group=group)
-        else:
-            xh_all, sq_all = xh, sq
-        Vg, row0 = world * V, rank * V
-        G = gemm(xh, xh_all, out_dtype=torch.float32)                       # [V, Vg] inner products, exact-fp32 MFMA
-        idx = torch.empty(V, dtype=torch.int32, device=dev)
-        dmin = f(V)
-        check(lib.dinox_koleo_nn(_p(G), Vg, _p(sq_all), _p(xh_all), row0, V, Vg, D, _p(idx), _p(dmin), _stream()), "dinox_koleo_nn")
-        if gather:
-            idx_all = torch.empty(Vg, dtype=torch.int32, device=dev)
-            d_all = f(Vg)
-            dist.all_gather_into_tensor(idx_all, idx, group=group)
-            dist.all_gather_into_tensor(d_all, dmin, group=group)
-        else:
-            idx_all, d_all = idx, dmin
-        ctx.save_for_backward(xh_all, idx_all, d_all, norm)
-        ctx.dims, ctx.eps = (row0, V, Vg, D), eps
-        return -torch.log(dmin + eps).mean()
+        loss, saved = koleo_fwd(x, eps, group)
+        ctx.saved = saved
+        return loss.reshape(())
 
     @staticmethod
     def backward(ctx, g):
-        xh_all, idx_all, d_all, norm = ctx.saved_tensors
-        row0, V, Vg, D = ctx.dims
-        dx = torch.empty((V, D), dtype=torch.float32, device=xh_all.device)
-        # the kernel takes the upstream gradient as a host scalar folded into gscale; keep it on the device instead: run with
-        # gscale = 1/V and scale the result by g (one small elementwise multiply, no host sync)
-        check(lib.dinox_koleo_bwd(_p(xh_all), _p(idx_all), _p(d_all), _p(norm), row0, V, Vg, D, 1.0 / V, ctx.eps, 1e-12, _p(dx), _stream()),
-              "dinox_koleo_bwd")
-        return dx * g, None, None
+        # the upstream gradient is a device scalar: run with gscale = 1 and scale the result (one small elementwise multiply, no host sync)
+        return koleo_bwd(ctx.saved, 1.0) * g, None, None
 
 
 def koleo_loss(x: Tensor, eps: float = 1e-8, group=None) -> Tensor:

@@ -258,6 +258,8 @@ int dinox_slice_views(const void* raw_u16, const int64_t* view_i, const float* v
 int dinox_koleo_normalize(const float* x, float* xh, float* norm, float* sq, int64_t V, int D, float eps, void* stream);
 int dinox_koleo_nn(const float* G, int64_t ldg, const float* sq_all, const float* xh_all, int row0, int V_l, int V_g, int D,
                    int* idx, float* dist, void* stream);
+/* loss[0] = -mean_i log(dist[i] + eps) over the V local rows (fixed summation order). */
+int dinox_koleo_loss(const float* dist, int V, float eps, float* loss, void* stream);
 int dinox_koleo_bwd(const float* xh_all, const int* idx_all, const float* dist_all, const float* norm_loc, int row0, int V_l,
                     int V_g, int D, float gscale, float eps, float norm_eps, float* dx, void* stream);
 

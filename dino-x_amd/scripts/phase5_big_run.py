@@ -272,8 +272,8 @@ class PngDataset(torch.utils.data.Dataset):
                 spacing = torch.tensor([row.spacing_x, row.spacing_y, row.spacing_z], dtype=torch.float32)
                 if self.raw_views:      # --gpu-views: ship the u16 stack and the draws of both views; dinox_slice_views does the rest
                     from dinox.views import draw_view
-                    stack = np.stack([np.asarray(sl, dtype=np.uint16) for sl in slices], 0)
-                    H, W = stack.shape[1:]
+                    stack = [np.asarray(sl, dtype=np.uint16) for sl in slices]          # collate_stacks writes the slices straight into the batch
+                    H, W = stack[0].shape
                     kw = dict(rw_level=(self.rw_level_min, self.rw_level_max), rw_width=(self.rw_width_min, self.rw_width_max),
                               crop_scale=self.crop_scale)
                     views = [draw_view(H, W, **kw), draw_view(H, W, **kw)]
@@ -295,6 +295,7 @@ class SyntheticSliceDataset(PngDataset):
         super().__init__(rows, img_size=img_size, **kw)
         self.raw = raw_size or int(img_size * 1.25)
         self.seed = seed
+        self._cache: dict = {}
         g = np.random.default_rng(seed)
         for r in rows:
             r.spacing_x = r.spacing_y = float(g.uniform(0.46, 0.98))
@@ -302,6 +303,13 @@ class SyntheticSliceDataset(PngDataset):
 
     def _stack(self, row: IndexRow) -> list:
         i = int(row.png_path.stem)
+        hit = self._cache.get(i)             # (per worker process) a stack is a pure function of its index: generate it once --
+        if hit is not None:                  # drawing 3 x raw^2 normals per item costs more host time than the step costs GPU time
+            return hit
+        self._cache[i] = out = self._make(i)
+        return out
+
+    def _make(self, i: int) -> list:
         g = np.random.default_rng(self.seed * 1_000_003 + i)
         base = g.integers(22768, 72768, size=(self.raw // 8 + 1, self.raw // 8 + 1)).astype(np.float32)
         img = np.kron(base, np.ones((8, 8), dtype=np.float32))[: self.raw, : self.raw]      # blocky "anatomy"
@@ -710,9 +718,12 @@ def main(argv=None) -> None:
     ds.raw_views = bool(args.gpu_views)
     ds.local_crops = int(args.local_crops)
     if args.gpu_views:
+        import dinox.views as _views
         from dinox.views import collate_stacks, make_views
-        say("gpu_views=True")
-    common = dict(num_workers=hw.num_workers, pin_memory=hw.pin_memory and not args.gpu_views, worker_init_fn=_worker_init,
+        if hw.pin_memory and hw.num_workers > 0:          # (before the workers are forked: they inherit the setting)
+            _views.SHM_RING = 4                           # prefetch_factor 2 + the batch being pinned + one spare
+        say(f"gpu_views=True shm_ring={_views.SHM_RING}")
+    common = dict(num_workers=hw.num_workers, pin_memory=hw.pin_memory, worker_init_fn=_worker_init,       # (StackBatch.pin_memory for --gpu-views)
                   collate_fn=collate_stacks if args.gpu_views else dino_collate, persistent_workers=hw.num_workers > 0)
     if len(ds) < args.batch_size * world:
         raise SystemExit(f"dataset size ({len(ds)}) is smaller than the global batch ({args.batch_size} x {world} ranks)")
@@ -725,7 +736,7 @@ def main(argv=None) -> None:
     if world > 1:
         sampler = ShardedBatchSampler(sampler, rank, world)
     dl = torch.utils.data.DataLoader(ds, batch_sampler=sampler, **common)
-    it = iter(dl)
+    it = None if args.gpu_views else iter(dl)
 
     # ---- model / engine
     vit_kw = dict(img_size=args.img_size, patch=model_cfg.patch, dim=model_cfg.dim, depth=model_cfg.depth, heads=model_cfg.heads,
@@ -756,7 +767,22 @@ def main(argv=None) -> None:
     say(f"Starting training from step {start_step} to {max_steps if args.max_steps else 'unlimited'}")
     say("─" * 80)
     step = start_step - 1
-    pending = None                      # (step, scalars) of the previous step, fetched one step late: no stall of the GPU queue
+    # (step, loss tensor, lr) of earlier steps, read back LOSS_LAG steps late: the device always has queued work while the host waits
+    # for data (one step of lag left the GPU idle ~5 ms per step whenever a batch arrived late; the logged values are the same)
+    LOSS_LAG = 2
+    pending: list = []
+    loss_pin = torch.empty(LOSS_LAG + 1, dtype=torch.float32).pin_memory() if device.type == "cuda" else None
+
+    def read_loss(ref) -> float:
+        if isinstance(ref, tuple):
+            slot, ev = ref
+            ev.synchronize()
+            return float(loss_pin[slot])
+        return float(ref)
+
+    prefetch = None
+    _prof = {"data": 0.0, "views": 0.0, "step": 0.0, "n": 0, "t0": time.time()}     # host time per phase: DINOX_CLI_PROFILE=<first step counted>
+    _prof_from = int(os.environ.get("DINOX_CLI_PROFILE") or 0)
     stop_every = 10                     # under DP the ranks agree on an interrupt only at these steps (one tiny all-reduce + sync)
     for step in range(start_step, int(max_steps)):
         if world > 1:
@@ -771,32 +797,67 @@ def main(argv=None) -> None:
             say("interrupt=true")
             step -= 1
             break
-        try:
-            item = next(it)
-        except StopIteration:
-            it = iter(dl)
-            item = next(it)
         loc = spl = None
         if args.gpu_views:
-            sb = item.to(device)
+            if prefetch is None:
+                from dinox.views import DevicePrefetcher
+                prefetch = DevicePrefetcher(dl, device)       # the next batch's stacks cross PCIe under this step
+                if _prof_from:
+                    prefetch.timing = []
+            _t0 = time.perf_counter()
+            sb = prefetch.next()
+            _prof["data"] += time.perf_counter() - _t0
+            if _prof_from:
+                if _prof.get("ev") is not None and _prof["ev"][1].query():
+                    _prof["gpu"] = _prof.get("gpu", 0.0) + _prof["ev"][0].elapsed_time(_prof["ev"][1])
+                    _prof["gpu_n"] = _prof.get("gpu_n", 0) + 1
+                _prof["ev"] = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                _prof["ev"][0].record()
+            _t0 = time.perf_counter()
             batch, spacing = make_views(sb, args.img_size, views=sb.views[:2]), sb.spacing
+            _prof["views"] += time.perf_counter() - _t0
             if args.local_crops:
                 loc = make_views(sb, args.local_size, views=sb.views[2:])
                 spl = torch.cat([spacing] * args.local_crops, 0) if args.scale_aware else None
         else:
+            try:
+                item = next(it)
+            except StopIteration:
+                it = iter(dl)
+                item = next(it)
             views, spacing = item
-            batch = torch.cat(views, 0).to(device, non_blocking=True)
+            # (each view batch is page-locked by the loader: copy first, concatenate on the device -- a host-side cat would make a pageable
+            #  tensor whose copy is synchronous)
+            batch = torch.cat([v.to(device, non_blocking=True) for v in views], 0)
         sp2 = torch.cat([spacing, spacing], 0).to(device, non_blocking=True) if args.scale_aware else None
+        _t0 = time.perf_counter()
         out = eng.step(batch, sp2, loc, spl)
+        _prof["step"] += time.perf_counter() - _t0
+        _prof["n"] += 1
+        _prof["t1"] = time.time()
+        if _prof_from and _prof.get("ev") is not None:
+            _prof["ev"][1].record()
+        if _prof_from and step == start_step + _prof_from:      # steady state only: drop what the start-up steps accumulated
+            _prof.update(data=0.0, views=0.0, step=0.0, n=0, t0=time.time(), gpu=0.0, gpu_n=0)
         loss_t = out["loss"]
         if world > 1:                   # the logged loss (and the NaN guard on it) is the global-batch mean, identical on every rank
             loss_t = loss_t.clone()
             torch.distributed.all_reduce(loss_t, op=torch.distributed.ReduceOp.SUM)
             loss_t = loss_t / world
-        cur = (step, loss_t, out["lr"])
-        # the loss of step s is read back while step s+1 is already queued
-        for (s_, loss_t, lr_) in ([pending] if pending is not None else []):
-            loss_val = float(loss_t)
+        # The loss of step s travels to a page-locked slot by an asynchronous copy and is read LOSS_LAG steps later, after waiting for ITS
+        # event only.  (float(tensor) / .item() synchronises the whole stream: with it the host could never run ahead of the device,
+        # which then idled for the ~7 ms the host needs to fetch and launch the next step.)
+        if loss_pin is not None:
+            slot = step % (LOSS_LAG + 1)
+            loss_pin[slot:slot + 1].copy_(loss_t.detach().reshape(1).float(), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            cur = (step, (slot, ev), out["lr"])
+        else:
+            cur = (step, loss_t, out["lr"])
+        pending.append(cur)
+        for (s_, loss_t, lr_) in ([pending.pop(0)] if len(pending) > LOSS_LAG else []):
+            loss_val = read_loss(loss_t)
             loss_history.append(loss_val)
             if args.log_json is not None and main_rank:
                 with open(args.log_json, "a") as jf:
@@ -815,15 +876,13 @@ def main(argv=None) -> None:
                 raise RuntimeError(msg)
             if bad:
                 say(f"⚠️  WARNING: {msg}")
-        pending = cur
         if (step + 1) % args.ckpt_every == 0 and main_rank:
             path = run_dir / f"checkpoint_{step + 1:08d}.pth"
             save_checkpoint(path, step + 1, student, teacher, eng, cfg)
             say(f"checkpoint_saved={path}")
             rotate_checkpoints(run_dir, args.ckpt_keep_last)
-    if pending is not None:
-        s_, loss_t, lr_ = pending
-        loss_val = float(loss_t)
+    for s_, loss_t, lr_ in pending:
+        loss_val = read_loss(loss_t)
         loss_history.append(loss_val)
         if args.log_json is not None and main_rank:
             with open(args.log_json, "a") as jf:
@@ -835,6 +894,15 @@ def main(argv=None) -> None:
         say(f"final_checkpoint={final}")
     say("─" * 80)
     say(f"Training complete: {final_step - start_step} steps in {time.time() - t0:.1f}s")
+    if os.environ.get("DINOX_CLI_PROFILE") and _prof["n"]:
+        n = _prof["n"]
+        say(f"host ms/step: wait for data {1e3 * _prof['data'] / n:.1f}, view parameters + launch {1e3 * _prof['views'] / n:.1f}, "
+            f"engine enqueue {1e3 * _prof['step'] / n:.1f}, wall {1e3 * (_prof.get('t1', time.time()) - _prof['t0']) / n:.1f} (over the last {n} steps); "
+            f"device time views + step {_prof.get('gpu', 0.0) / max(_prof.get('gpu_n', 0), 1):.1f} ms")
+        if prefetch is not None and prefetch.timing:
+            torch.cuda.synchronize()
+            ts = sorted(a.elapsed_time(b) for a, b in prefetch.timing[-200:])
+            say(f"H2D copy of a batch on the copy stream: median {ts[len(ts) // 2]:.1f} ms, max {ts[-1]:.1f} ms ({sb.raw.numel() * 2 / 1e6:.0f} MB)")
     say(f"Final loss: {loss_history[-1]:.4f}" if loss_history else "Final loss: N/A")
     if world > 1:
         torch.distributed.barrier()

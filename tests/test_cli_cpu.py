@@ -196,3 +196,35 @@ def test_sharded_batch_sampler_partitions_global_batches(cli):
         shards.append(list(cli.ShardedBatchSampler(inner, rank, 2)))
     flat = [j for p in shards for b in p for j in b]
     assert len(flat) == len(set(flat)) == n and all(len(b) == 4 for p in shards for b in p)
+
+
+def test_collate_stacks_shared_ring_and_slice_form(cli):
+    """--gpu-views host path: `collate_stacks` takes a stack as a (3,H,W) array or as its three (H,W) slices and writes them into one flat
+    buffer; inside a DataLoader worker that buffer is a shared-memory tensor from a per-worker ring (views.SHM_RING) -- reused storage, same
+    bytes.  The synthetic dataset's stacks are a function of the index, so every batch can be checked against a direct rebuild."""
+    import dinox.views as V
+    ds = cli.SyntheticSliceDataset(24, img_size=32)
+    ds.raw_views, ds.local_crops = True, 0
+    items = [ds[i] for i in range(6)]
+    assert isinstance(items[0][0], list) and len(items[0][0]) == 3 and items[0][0][0].dtype == np.uint16
+    want = np.concatenate([np.stack(s, 0).reshape(-1) for s, _, _ in items]).view(np.int16)
+    a = V.collate_stacks(items)
+    b = V.collate_stacks([(np.stack(s, 0), v, sp) for s, v, sp in items])
+    assert np.array_equal(a.raw.numpy(), want) and np.array_equal(b.raw.numpy(), want)
+    assert a.offsets == b.offsets == [i * 3 * 40 * 40 for i in range(6)] and a.shapes == [(40, 40)] * 6 and len(a.views) == 2
+    assert a.pin_memory is not None and a.spacing.shape == (6, 3)
+    old = V.SHM_RING
+    V.SHM_RING = 4          # > prefetch_factor (2) + 1: a worker is never more than two batches ahead of the one being read
+    try:
+        sampler = torch.utils.data.BatchSampler(torch.utils.data.SequentialSampler(ds), batch_size=4, drop_last=True)
+        dl = torch.utils.data.DataLoader(ds, batch_sampler=sampler, num_workers=1, collate_fn=V.collate_stacks, persistent_workers=True)
+        seen = []
+        for epoch in range(2):
+            for k, batch in enumerate(dl):
+                assert batch.raw.is_shared()
+                ref = np.concatenate([np.stack(ds._make(4 * k + j), 0).reshape(-1) for j in range(4)]).view(np.int16)
+                assert np.array_equal(batch.raw.numpy(), ref), (epoch, k)
+                seen.append(batch.raw.untyped_storage().data_ptr() if hasattr(batch.raw, "untyped_storage") else 0)
+        assert len(seen) == 12
+    finally:
+        V.SHM_RING = old

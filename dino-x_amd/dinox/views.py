@@ -79,13 +79,13 @@ class StackBatch:
     def pin_memory(self) -> "StackBatch":
         """Called by the DataLoader's pinning thread (pin_memory=True): page-locked copies, so that ``to(device)`` is a true
         asynchronous DMA instead of a staged copy that blocks the host."""
-        if self.raw.is_shared():
+        if SHM_RING > 0 and self.raw.is_shared():      # (ring only: with a fresh shared tensor per batch this would pin them all down)
             # keep the worker's ring buffer MAPPED in this process: torch finds a shared storage it already holds by its file identity,
             # a dropped one is unmapped and mapped again for the next batch in it (120 MB of page-table faults per batch)
             st = self.raw.untyped_storage()
             _mapped[st.data_ptr()] = st
             _mapped.move_to_end(st.data_ptr())
-            while len(_mapped) > 256:
+            while len(_mapped) > 128:
                 _mapped.popitem(last=False)
         return StackBatch(self.raw.pin_memory(), self.offsets, self.shapes, self.views, self.spacing.pin_memory())
 

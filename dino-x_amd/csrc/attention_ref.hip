@@ -166,6 +166,47 @@ __global__ __launch_bounds__(AR_THREADS) void attn_ref_bwd_dkv(const void* __res
   }
 }
 
+// ------------------------------------------------------------------------------------------ rows of a materialised score matrix
+// The fp32 parity mode at full size runs attention as batched exact-fp32 products (S = scale Q K^T, O = P V, and the five products of the
+// backward pass) with the softmax on the materialised [rows][n] scores in between: the per-lane kernels above take 23 ms per layer at bs 64.
+// One wave per row; rows are (image, query) pairs of ONE head; lse lives in the [B][heads][N] tensor of the attention API.
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ s, float* __restrict__ lse, int64_t rows, int n,
+                                                           int rows_per_image, int64_t lse_image_stride) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  float* row = s + r * n;
+  float mx = -INFINITY;
+  for (int j = lane; j < n; j += 64) mx = fmaxf(mx, row[j]);
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int j = lane; j < n; j += 64) sum += __expf(row[j] - mx);
+  sum = wave_sum(sum);
+  const float l = mx + __logf(sum);
+  for (int j = lane; j < n; j += 64) row[j] = __expf(row[j] - l);
+  if (lane == 0) lse[(r / rows_per_image) * lse_image_stride + (r % rows_per_image)] = l;
+}
+
+// p = exp(s - lse) (in place of s), ds = p * (dp - sum_j p_j dp_j) * scale (in place of dp)
+__global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(float* __restrict__ s, float* __restrict__ dp, const float* __restrict__ lse,
+                                                               float scale, int64_t rows, int n, int rows_per_image,
+                                                               int64_t lse_image_stride) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  float* srow = s + r * n;
+  float* drow = dp + r * n;
+  const float l = lse[(r / rows_per_image) * lse_image_stride + (r % rows_per_image)];
+  float dot = 0.f;
+  for (int j = lane; j < n; j += 64) {
+    const float p = __expf(srow[j] - l);
+    srow[j] = p;
+    dot += p * drow[j];
+  }
+  dot = wave_sum(dot);
+  for (int j = lane; j < n; j += 64) drow[j] = srow[j] * (drow[j] - dot) * scale;
+}
+
 int launch_attention_ref_fwd(const void* qkv, void* o, float* lse, int B, int N, int heads, int d, int dtype,
                              hipStream_t st) {
   dim3 grid((unsigned)(B * heads), (unsigned)ceil_div(N, AR_ROWS));
@@ -197,3 +238,20 @@ int launch_attention_ref_bwd(const void* d_o, const void* qkv, const void* o, co
 }
 
 }  // namespace dinox
+
+extern "C" int dinox_softmax_rows(float* s, float* lse, int64_t rows, int n, int rows_per_image, int64_t lse_image_stride, void* stream) {
+  DX_REQUIRE(s && lse, DINOX_EINVAL, "softmax_rows: null pointer");
+  DX_REQUIRE(rows > 0 && n > 0 && rows_per_image > 0, DINOX_EINVAL, "softmax_rows: rows=%lld n=%d", (long long)rows, n);
+  hipLaunchKernelGGL(dinox::softmax_rows_kernel, dim3((unsigned)dinox::ceil_div(rows, (int64_t)4)), dim3(256), 0, dinox::as_stream(stream), s, lse, rows, n,
+                     rows_per_image, lse_image_stride);
+  return dinox::check_launch("softmax_rows");
+}
+
+extern "C" int dinox_softmax_bwd_rows(float* s, float* dp, const float* lse, float scale, int64_t rows, int n, int rows_per_image,
+                                      int64_t lse_image_stride, void* stream) {
+  DX_REQUIRE(s && dp && lse, DINOX_EINVAL, "softmax_bwd_rows: null pointer");
+  DX_REQUIRE(rows > 0 && n > 0 && rows_per_image > 0, DINOX_EINVAL, "softmax_bwd_rows: rows=%lld n=%d", (long long)rows, n);
+  hipLaunchKernelGGL(dinox::softmax_bwd_rows_kernel, dim3((unsigned)dinox::ceil_div(rows, (int64_t)4)), dim3(256), 0, dinox::as_stream(stream), s, dp, lse,
+                     scale, rows, n, rows_per_image, lse_image_stride);
+  return dinox::check_launch("softmax_bwd_rows");
+}

@@ -220,6 +220,27 @@ def gemm(A: Tensor, B: Tensor, *, transA=False, transB=False, out: Optional[Tens
         strideA=a2[0] * a2[1] if batched else 0, strideB=(b2[0] * b2[1] if (batched and B.dim() == 3) else 0),
         strideC=M * N, transA=int(transA), transB=int(transB), in_dtype=_code(A.dtype), out_dtype=_code(odt),
         epilogue=epi, alpha=alpha, bias=_p(bias), residual=_p(residual), ldr=N, aux=_p(aux), ldaux=N, colsum=_p(colsum_out), ws=None)
+    if (transA and transB and not batched and A.dtype == torch.float32 and odt == torch.float32 and K >= 4096
+            and not (epi & ~EPI_ACCUM) and ((M + 127) // 128) * ((N + 127) // 128) < 256):
+        # fp32 dW products (parity mode): [M x N] is a few dozen tiles with the whole token axis as reduction -- 36 workgroups on 256 CUs,
+        # 3-12 ms per launch.  Cut the reduction into chunks that run as ONE batched launch and meet in the fixed-order column sum.
+        tiles = ((M + 127) // 128) * ((N + 127) // 128)
+        splits = max(1, min(K // 1024, 1024 // tiles))
+        while splits > 1 and K % splits:
+            splits -= 1
+        if splits > 1:
+            kc = K // splits
+            part = torch.empty((splits, M, N), dtype=torch.float32, device=A.device)
+            g2 = GemmArgs(A=_p(A), B=_p(B), C=_p(part), M=M, N=N, K=kc, lda=a2[1], ldb=b2[1], ldc=N, batch=splits, strideA=kc * a2[1],
+                          strideB=kc * b2[1], strideC=M * N, transA=1, transB=1, in_dtype=F32, out_dtype=F32, epilogue=0, alpha=alpha,
+                          bias=None, residual=None, ldr=N, aux=None, ldaux=N, colsum=None, ws=None)
+            if TRACE_KERNELS is not None:
+                TRACE_KERNELS.append(lib.dinox_gemm_kernel_name(C.byref(g2)).decode())
+            check(lib.dinox_gemm(C.byref(g2), _stream()), "dinox_gemm")
+            colsum(part.view(splits, M * N), out=out.view(-1), accumulate=accumulate)
+            if colsum_out is not None:                       # A is stored [K][M]: its column sums are the bias gradient
+                check(lib.dinox_colsum(_p(A), _p(colsum_out), K, M, a2[1], F32, int(accumulate), _stream()), "dinox_colsum")
+            return out
     if transA and transB and not batched and A.dtype == torch.bfloat16 and not _TN_ATOMICS:
         need = lib.dinox_gemm_ws_bytes(C.byref(g))       # split-K dW product: deterministic two-stage reduction through a workspace
         if need:
@@ -493,6 +514,64 @@ def layernorm_bwd(dy: Tensor, x: Tensor, w: Tensor, mean: Tensor, rstd: Tensor, 
     return dx, dw, db, lowp
 
 
+_ATTN_F32_REF = bool(os.environ.get("DINOX_ATTN_F32_REF"))      # fp32 attention by the per-lane reference kernels whatever the size (A/B, tests)
+
+
+def _gemm_f32_raw(a: int, b: int, c: int, M: int, N: int, K: int, lda: int, ldb: int, ldc: int, batch: int, sa: int, sb: int, sc: int,
+                  ta: bool, tb: bool, alpha: float = 1.0) -> None:
+    """One batched exact-fp32 product on raw addresses and element strides (operands are slices of packed tensors: no copies)."""
+    g = GemmArgs(A=a, B=b, C=c, M=M, N=N, K=K, lda=lda, ldb=ldb, ldc=ldc, batch=batch, strideA=sa, strideB=sb, strideC=sc,
+                 transA=int(ta), transB=int(tb), in_dtype=F32, out_dtype=F32, epilogue=0, alpha=alpha, bias=None, residual=None, ldr=N,
+                 aux=None, ldaux=N, colsum=None, ws=None)
+    check(lib.dinox_gemm(C.byref(g), _stream()), "dinox_gemm")
+
+
+def _use_f32_products(qkv: Tensor, N: int, d: int) -> bool:
+    # full-size fp32 attention: batched exact-fp32 products + softmax rows (the per-lane reference kernels take 4.3 / 32 ms per layer
+    # forward / backward at bs 64; this form 0.7 / 1.7 ms).  Small problems keep the reference kernels (fewer launches).
+    return qkv.dtype == torch.float32 and not _ATTN_F32_REF and N >= 32 and qkv.shape[0] * N >= 4096
+
+
+def _attention_fwd_f32_products(qkv: Tensor, heads: int, o: Tensor, lse: Tensor) -> None:
+    """softmax(Q K^T / sqrt(d)) V per head as S = scale Q K^T (NT), softmax rows, O = P V -- operands addressed inside the packed qkv
+    [B, N, 3, heads, d] and o [B, N, heads, d] by leading dimensions and batch strides."""
+    B, N, C3 = qkv.shape
+    Cc = C3 // 3
+    d = Cc // heads
+    scale = 1.0 / math.sqrt(d)
+    S = torch.empty((B, N, N), dtype=torch.float32, device=qkv.device)
+    q0, o0, E = qkv.data_ptr(), o.data_ptr(), 4
+    for h in range(heads):
+        qh, kh, vh = q0 + E * h * d, q0 + E * (Cc + h * d), q0 + E * (2 * Cc + h * d)
+        _gemm_f32_raw(qh, kh, _p(S), N, N, d, C3, C3, N, B, N * C3, N * C3, N * N, False, False, scale)          # S[b] = scale Q K^T
+        check(lib.dinox_softmax_rows(_p(S), lse.data_ptr() + E * h * N, B * N, N, N, heads * N, _stream()), "dinox_softmax_rows")
+        _gemm_f32_raw(_p(S), vh, o0 + E * h * d, N, d, N, N, C3, Cc, B, N * N, N * C3, N * Cc, False, True)      # O[b] = P V
+
+
+def _attention_bwd_f32_products(do: Tensor, qkv: Tensor, o: Tensor, lse: Tensor, heads: int, dqkv: Tensor) -> None:
+    """Backward of the same: P = exp(S - lse) recomputed per head, dP = dO V^T, dS = P o (dP - rowsum(P o dP)) * scale, then
+    dV = P^T dO, dQ = dS K, dK = dS^T Q written straight into the packed dqkv."""
+    B, N, C3 = qkv.shape
+    Cc = C3 // 3
+    d = Cc // heads
+    scale = 1.0 / math.sqrt(d)
+    dev = qkv.device
+    S = torch.empty((B, N, N), dtype=torch.float32, device=dev)
+    dP = torch.empty((B, N, N), dtype=torch.float32, device=dev)
+    q0, g0, do0, E = qkv.data_ptr(), dqkv.data_ptr(), do.data_ptr(), 4
+    for h in range(heads):
+        qh, kh, vh = q0 + E * h * d, q0 + E * (Cc + h * d), q0 + E * (2 * Cc + h * d)
+        dqh, dkh, dvh = g0 + E * h * d, g0 + E * (Cc + h * d), g0 + E * (2 * Cc + h * d)
+        doh = do0 + E * h * d
+        _gemm_f32_raw(qh, kh, _p(S), N, N, d, C3, C3, N, B, N * C3, N * C3, N * N, False, False, scale)          # S = scale Q K^T
+        _gemm_f32_raw(doh, vh, _p(dP), N, N, d, Cc, C3, N, B, N * Cc, N * C3, N * N, False, False)               # dP = dO V^T
+        check(lib.dinox_softmax_bwd_rows(_p(S), _p(dP), lse.data_ptr() + E * h * N, scale, B * N, N, N, heads * N, _stream()),
+              "dinox_softmax_bwd_rows")                                                                              # S <- P, dP <- dS
+        _gemm_f32_raw(_p(S), doh, dvh, N, d, N, N, Cc, C3, B, N * N, N * Cc, N * C3, True, True)                  # dV = P^T dO
+        _gemm_f32_raw(_p(dP), kh, dqh, N, d, N, N, C3, C3, B, N * N, N * C3, N * C3, False, True)                 # dQ = dS K
+        _gemm_f32_raw(_p(dP), qh, dkh, N, d, N, N, C3, C3, B, N * N, N * C3, N * C3, True, True)                  # dK = dS^T Q
+
+
 def attention_fwd(qkv: Tensor, heads: int):
     _need_cuda(qkv)
     qkv = _c(qkv)
@@ -501,6 +580,9 @@ def attention_fwd(qkv: Tensor, heads: int):
     d = Cc // heads
     o = torch.empty((B, N, Cc), dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty((B, heads, N), dtype=torch.float32, device=qkv.device)
+    if _use_f32_products(qkv, N, d):
+        _attention_fwd_f32_products(qkv, heads, o, lse)
+        return o, lse
     check(lib.dinox_attention_fwd(_p(qkv), _p(o), _p(lse), B, N, heads, d, _code(qkv.dtype), _stream()), "dinox_attention_fwd")
     return o, lse
 
@@ -510,6 +592,9 @@ def attention_bwd(do: Tensor, qkv: Tensor, o: Tensor, lse: Tensor, heads: int) -
     B, N, C3 = qkv.shape
     d = C3 // 3 // heads
     dqkv = torch.empty_like(qkv)
+    if _use_f32_products(qkv, N, d):
+        _attention_bwd_f32_products(_c(do), _c(qkv), o, lse, heads, dqkv)
+        return dqkv
     ws = torch.empty(lib.dinox_attention_bwd_ws_bytes(B, N, heads), dtype=torch.uint8, device=qkv.device)
     check(lib.dinox_attention_bwd(_p(do), _p(qkv), _p(o), _p(lse), _p(dqkv), _p(ws), B, N, heads, d, _code(qkv.dtype), _stream()),
           "dinox_attention_bwd")

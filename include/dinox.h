@@ -155,6 +155,14 @@ int dinox_layernorm_bwd(const void* dy, const float* x, const float* w, const fl
  * ------------------------------------------------------------------------------------------ */
 int dinox_attention_fwd(const void* qkv, void* o, float* lse, int B, int N, int heads, int d, int dtype,
                         void* stream);
+/* Rows of a materialised fp32 score matrix [rows][n] (rows = (image, query) pairs of one head; row r's log-sum-exp lives at
+ * lse[(r / rows_per_image) * lse_image_stride + r % rows_per_image], i.e. inside the [B][heads][N] tensor of the calls above):
+ *   softmax_rows:     s <- softmax(s) in place, lse written;
+ *   softmax_bwd_rows: s <- p = exp(s - lse), dp <- ds = p * (dp - sum_j p_j dp_j) * scale, both in place.
+ * Used by the fp32 parity mode, which runs full-size attention as batched exact-fp32 products around these two. */
+int dinox_softmax_rows(float* s, float* lse, int64_t rows, int n, int rows_per_image, int64_t lse_image_stride, void* stream);
+int dinox_softmax_bwd_rows(float* s, float* dp, const float* lse, float scale, int64_t rows, int n, int rows_per_image,
+                           int64_t lse_image_stride, void* stream);
 int64_t dinox_attention_bwd_ws_bytes(int B, int N, int heads);
 int dinox_attention_bwd(const void* d_o, const void* qkv, const void* o, const float* lse, void* dqkv, void* ws,
                         int B, int N, int heads, int d, int dtype, void* stream);

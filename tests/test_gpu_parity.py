@@ -1594,6 +1594,52 @@ def test_empty_batch_is_a_no_op_like_the_reference(dx):
         m(torch.empty(0, 3, 64, 64))
 
 
+def test_fp32_mode_fast_paths_equal_the_reference_kernels(dx):
+    """The fp32 parity mode at full size runs (a) attention as batched exact-fp32 products around softmax row kernels instead of the
+    per-lane reference kernels, (b) dW products with the token axis cut into chunks (one batched launch + the fixed-order column sum),
+    (c) Linear products on 128 x 128 tiles.  Each must agree with the small-size form it replaces: (a) to fp32 round-off of a different
+    summation order, (b) likewise, (c) bit for bit (same k-ordered chain per output)."""
+    ops, _ = dx
+    g = torch.Generator(device="cuda").manual_seed(11)
+    B, N, H = 24, 201, 6                                            # 24 x 201 = 4824 rows: above the size where the product form takes over
+    qkv = torch.randn(B, N, 3 * H * 64, device="cuda", generator=g) * 0.5
+    do = torch.randn(B, N, H * 64, device="cuda", generator=g) * 0.1
+    assert ops._use_f32_products(qkv, N, 64)
+    o1, l1 = ops.attention_fwd(qkv, H)
+    d1 = ops.attention_bwd(do, qkv, o1, l1, H)
+    ops._ATTN_F32_REF = True
+    try:
+        assert not ops._use_f32_products(qkv, N, 64)
+        o0, l0 = ops.attention_fwd(qkv, H)
+        d0 = ops.attention_bwd(do, qkv, o0, l0, H)
+    finally:
+        ops._ATTN_F32_REF = False
+    close(o1, o0, 1e-5, 1e-6, "fp32 attention o")
+    close(l1, l0, 1e-6, 1e-6, "fp32 attention lse")
+    close(d1, d0, 2e-5, 1e-6, "fp32 attention dqkv")
+    # (b) dW = dy^T x with K = 16384 tokens, accumulated into an existing gradient, with the bias gradient
+    K, M, Nn = 16384, 384, 256
+    dy, x = torch.randn(K, M, device="cuda", generator=g), torch.randn(K, Nn, device="cuda", generator=g)
+    base, bb = torch.randn(M, Nn, device="cuda", generator=g), torch.randn(M, device="cuda", generator=g)
+    got, gb = base.clone(), bb.clone()
+    ops.TRACE_KERNELS = []
+    try:
+        ops.gemm(dy, x, transA=True, transB=True, out=got, accumulate=True, colsum_out=gb)
+        assert len(ops.TRACE_KERNELS) == 1                          # one batched launch
+    finally:
+        ops.TRACE_KERNELS = None
+    want = base.double() + dy.double().t() @ x.double()
+    close(got, want, 2e-6, 1e-4, "fp32 split-K dW")
+    close(gb, bb.double() + dy.double().sum(0), 2e-6, 1e-4, "fp32 split-K db")
+    # (c) 128 x 128 tiles vs 64 x 64 tiles: M = 4096 rows takes the big tiles, the same rows in two halves of 64... compare with the product of a
+    # row subset small enough for the 64 x 64 kernel (N = 64 < 128)
+    a = torch.randn(4096, 512, device="cuda", generator=g)
+    w = torch.randn(1024, 512, device="cuda", generator=g)
+    big = ops.gemm(a, w)                                            # 32 x 8 = 256 tiles of 128 x 128
+    small = torch.cat([ops.gemm(a, w[i:i + 64].contiguous()) for i in range(0, 1024, 64)], 1)     # N = 64 per product: 64 x 64 tiles
+    assert torch.equal(big, small)
+
+
 def test_bench_launches_its_own_ranks(dx):
     """`python bench.py --gpus 2` started plainly (no torchrun) spawns its two ranks as child processes itself -- before the parent
     has touched the GPU -- and relays rank 0's line.  Here both ranks share this box's one GPU over gloo (RCCL wants a GPU per

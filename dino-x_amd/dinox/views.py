@@ -96,13 +96,14 @@ class DevicePrefetcher:
     been told to wait for, and starts the copy of the one after.  Restarts the loader at the end of an epoch (the training loop is
     step-driven, as in the reference)."""
 
-    def __init__(self, loader, device) -> None:
-        self.loader, self.device = loader, torch.device(device)
+    def __init__(self, loader, device, ahead: bool = True) -> None:
+        self.loader, self.device, self.run_ahead = loader, torch.device(device), ahead
         self.it = iter(loader)
         self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
         self.ahead = None
         self.timing = None           # a list -> (start, end) events of every copy (the training script's DINOX_CLI_PROFILE)
-        self._start()
+        # (the loader iterator is created HERE -- that draws the loader's base seed from torch's global generator, and the training script
+        #  creates it at the same point of its start-up as the reference creates its iterator; the first batch is fetched on first use)
 
     def _host_next(self):
         try:
@@ -128,6 +129,10 @@ class DevicePrefetcher:
         self.ahead = (dev, ev)
 
     def next(self) -> StackBatch:
+        if not self.run_ahead:                           # (A/B and the draw-order test: fetch, copy and hand out in program order)
+            return self._host_next().to(self.device)
+        if self.ahead is None:
+            self._start()
         dev, ev = self.ahead
         if ev is not None:
             cur = torch.cuda.current_stream(self.device)

@@ -736,7 +736,14 @@ def main(argv=None) -> None:
     if world > 1:
         sampler = ShardedBatchSampler(sampler, rank, world)
     dl = torch.utils.data.DataLoader(ds, batch_sampler=sampler, **common)
-    it = None if args.gpu_views else iter(dl)
+    # (iter(dl) draws the loader's base seed from torch's global generator: both pipelines do it here, before the model is initialised,
+    #  so that the same --train-seed gives the same initial weights with and without --gpu-views)
+    it, prefetch = None, None
+    if args.gpu_views:
+        from dinox.views import DevicePrefetcher
+        prefetch = DevicePrefetcher(dl, device, ahead=not os.environ.get("DINOX_NO_PREFETCH"))     # the next batch crosses PCIe under this step
+    else:
+        it = iter(dl)
 
     # ---- model / engine
     vit_kw = dict(img_size=args.img_size, patch=model_cfg.patch, dim=model_cfg.dim, depth=model_cfg.depth, heads=model_cfg.heads,
@@ -780,7 +787,6 @@ def main(argv=None) -> None:
             return float(loss_pin[slot])
         return float(ref)
 
-    prefetch = None
     _prof = {"data": 0.0, "views": 0.0, "step": 0.0, "n": 0, "t0": time.time()}     # host time per phase: DINOX_CLI_PROFILE=<first step counted>
     _prof_from = int(os.environ.get("DINOX_CLI_PROFILE") or 0)
     stop_every = 10                     # under DP the ranks agree on an interrupt only at these steps (one tiny all-reduce + sync)
@@ -799,11 +805,8 @@ def main(argv=None) -> None:
             break
         loc = spl = None
         if args.gpu_views:
-            if prefetch is None:
-                from dinox.views import DevicePrefetcher
-                prefetch = DevicePrefetcher(dl, device)       # the next batch's stacks cross PCIe under this step
-                if _prof_from:
-                    prefetch.timing = []
+            if _prof_from and prefetch.timing is None:
+                prefetch.timing = []
             _t0 = time.perf_counter()
             sb = prefetch.next()
             _prof["data"] += time.perf_counter() - _t0

@@ -155,3 +155,36 @@ def test_cli_multicrop_runs(cli, tmp_path):
     assert [l["step"] for l in lines] == [0, 1, 2, 3] and all(np.isfinite(l["loss"]) for l in lines)
     with pytest.raises(SystemExit, match="needs --gpu-views"):
         cli.main(["--config", "vit-tiny", "--synthetic", "16", "--local-crops", "2", "--max-steps", "1", "--run-dir", str(tmp_path / "x")])
+
+
+@pytest.mark.gpu
+def test_cli_two_ranks_gpu_views(tmp_path):
+    """The training script itself under data parallelism: two ranks (gloo; both on this box's one GPU -- RCCL wants a GPU per rank) with
+    --gpu-views, loader workers (shared-memory ring, pinned batches, device prefetcher), KoLeo over the global batch and gradient
+    accumulation.  Both ranks must finish, rank 0 alone writes the log and the checkpoints, the logged loss (all-reduced mean) is finite,
+    and a second identical launch reproduces it."""
+    import json, os, socket, subprocess, sys
+    from conftest import ROOT
+    script = os.path.join(ROOT, "dino-x_amd", "scripts", "phase5_big_run.py")
+
+    def launch(tag):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        log = tmp_path / f"{tag}.jsonl"
+        args = [sys.executable, script, "--config", "vit-tiny", "--vit-patch", "16", "--vit-dim", "64", "--vit-depth", "2", "--vit-heads", "2",
+                "--out-dim", "256", "--img-size", "32", "--batch-size", "4", "--scale-aware", "--amp", "--synthetic", "64", "--num-workers", "2",
+                "--warmup-steps", "2", "--lr", "1e-3", "--max-steps", "6", "--ckpt-every", "3", "--koleo-weight", "0.1", "--accumulation-steps", "2",
+                "--gpu-views", "--log-json", str(log), "--run-dir", str(tmp_path / tag)]
+        env = dict(os.environ, DINOX_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2")
+        procs = [subprocess.Popen(args, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+        outs = [p.communicate(timeout=300)[0].decode(errors="replace") for p in procs]
+        assert all(p.returncode == 0 for p in procs), "\n".join(o[-1500:] for o in outs)
+        lines = [json.loads(l) for l in log.read_text().splitlines()]
+        assert [l["step"] for l in lines] == list(range(6)) and all(np.isfinite(l["loss"]) for l in lines)      # written by rank 0 only, once per step
+        assert "final_checkpoint=" in outs[0] and "final_checkpoint=" not in outs[1]
+        assert "shm_ring=4" in outs[0]
+        runs = sorted((tmp_path / tag).iterdir())
+        assert len(runs) == 1 and any(f.name.startswith("checkpoint_final_") for f in runs[0].iterdir())
+        return [l["loss"] for l in lines]
+
+    a, b = launch("a"), launch("b")
+    assert a == pytest.approx(b, rel=1e-3)

@@ -91,7 +91,7 @@ def cpu_baseline(cfg_kw, out_dim, seconds_budget=25.0):
             "sample": f"oracle train_step (fp32 torch CPU), ViT-S/16 224 scale-aware, B={B} samples/step, {n} timed steps after 1 warm-up"}
 
 
-def framework_baseline(cfg_kw, out_dim, dev, B=256, steps=5):
+def framework_baseline(cfg_kw, out_dim, dev, B=256, steps=5, amp=True):
     """The SAME oracle step (the reference's loop restated in plain torch: its modules' functionals, its per-parameter grad-norm /
     AdamW / EMA loops) with every tensor on this GPU and the forward under torch.autocast(bfloat16) -- i.e. what the reference
     itself would do on this MI355X through PyTorch-ROCm (hipBLASLt GEMMs, the framework's SDPA / LayerNorm / optimizer kernels),
@@ -112,17 +112,17 @@ def framework_baseline(cfg_kw, out_dim, dev, B=256, steps=5):
     O._AMP["device"] = "cuda"
     try:
         for _ in range(2):
-            O.train_step(st, batch, sp2, hp, amp=True)
+            O.train_step(st, batch, sp2, hp, amp=amp)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
-            O.train_step(st, batch, sp2, hp, amp=True)
+            O.train_step(st, batch, sp2, hp, amp=amp)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
     finally:
         O._AMP["device"] = old
     return {"value": round(B * steps / dt, 2), "unit": "samples/s", "ms_per_step": round(1e3 * dt / steps, 2), "kind": "port", "device": "this GPU",
-            "sample": f"oracle train_step on cuda under torch.autocast(bfloat16) (torch {torch.__version__}: plain PyTorch-ROCm kernels), ViT-S/16 224 "
+            "sample": f"oracle train_step on cuda {'under torch.autocast(bfloat16)' if amp else 'in fp32 (no autocast)'} (torch {torch.__version__}: plain PyTorch-ROCm kernels), ViT-S/16 224 "
                       f"scale-aware, B={B} samples/step, {steps} timed steps after 2 warm-up"}
 
 
@@ -405,12 +405,12 @@ def main() -> None:
             note("timing the CPU oracle (cpu_baseline) ...")
             vit_s = dict(img_size=224, patch=16, dim=384, depth=12, heads=6, num_registers=4, scale_aware=True)
             line["cpu_baseline"] = cpu_baseline(vit_s, 8192) if args.model == "vit-small" else None
-            if args.model == "vit-small" and default_cfg:
+            if args.model == "vit-small" and (default_cfg or (args.fp32 and not L and not args.no_scale_aware)):     # (--fp32: the no-"--amp" comparison, any batch size)
                 try:
                     wl = None
                     torch.cuda.empty_cache()
                     note("timing the oracle step on this GPU through plain PyTorch-ROCm (framework_baseline) ...")
-                    line["framework_baseline"] = framework_baseline(vit_s, 8192, dev)
+                    line["framework_baseline"] = framework_baseline(vit_s, 8192, dev, B=B, steps=5 if not args.fp32 else 3, amp=not args.fp32)
                     line["framework_baseline"]["speedup"] = round(line["value"] / line["framework_baseline"]["value"], 2)
                 except Exception as e:                            # a baseline must never cost the headline line
                     line["framework_baseline"] = {"error": f"{type(e).__name__}: {e}"[:300]}

@@ -108,9 +108,7 @@ def framework_baseline(cfg_kw, out_dim, dev, B=256, steps=5, amp=True):
     sp = torch.rand(B, 3, device=dev, generator=g) * 0.5 + 0.5
     sp2 = torch.cat([sp, sp], 0)
     hp = O.HyperParams()
-    old = O._AMP["device"]
-    O._AMP["device"] = "cuda"
-    try:
+    with O.autocast_device("cuda"):
         for _ in range(2):
             O.train_step(st, batch, sp2, hp, amp=amp)
         torch.cuda.synchronize()
@@ -119,8 +117,6 @@ def framework_baseline(cfg_kw, out_dim, dev, B=256, steps=5, amp=True):
             O.train_step(st, batch, sp2, hp, amp=amp)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-    finally:
-        O._AMP["device"] = old
     return {"value": round(B * steps / dt, 2), "unit": "samples/s", "ms_per_step": round(1e3 * dt / steps, 2), "kind": "port", "device": "this GPU",
             "sample": f"oracle train_step on cuda {'under torch.autocast(bfloat16)' if amp else 'in fp32 (no autocast)'} (torch {torch.__version__}: plain PyTorch-ROCm kernels), ViT-S/16 224 "
                       f"scale-aware, B={B} samples/step, {steps} timed steps after 2 warm-up"}

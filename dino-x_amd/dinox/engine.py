@@ -309,11 +309,9 @@ class TrainEngine:
             # so the exchange runs under the backward pass)
             bm = ops.colmean(t_out)
             bm_work = dist.all_reduce(bm, op=dist.ReduceOp.SUM, group=self.group, async_op=True) if exchanging(self.group) else None
-            l_koleo = None
-            if hp.koleo_weight > 0.0:                        # :1764-1766; nearest neighbours over the global batch under DP
-                l_koleo, ksaved = ops.koleo_fwd(s_all[:V], group=self.group)
-                ops.axpy_(ds[:V], ops.koleo_bwd(ksaved, hp.koleo_weight * scale), 1.0)      # (ds[:V]: the leading rows, contiguous)
-            dcls = self._head_backward(self.student.head, saved, ds)
+            # KoLeo (:1764-1766; nearest neighbours over the global batch under DP): its all-gather of the unit rows is started here and
+            # awaited after the Gram loss, which has no data in common with it (nor with the head's backward)
+            kstate = ops.koleo_begin(s_all[:V], group=self.group) if hp.koleo_weight > 0.0 else None
             dfeats = torch.empty_like(sf)
             l_gram = None
             if hp.gram_weight != 0.0:
@@ -321,6 +319,11 @@ class TrainEngine:
                 ops.gram_loss_bwd(gsaved, tuple(sf.shape), hp.gram_weight * scale, dfeats=dfeats, accumulate=False)   # rows 1..N-1
             else:
                 ops.zero_(dfeats)
+            l_koleo = None
+            if kstate is not None:
+                l_koleo, ksaved = ops.koleo_end(kstate)
+                ops.axpy_(ds[:V], ops.koleo_bwd(ksaved, hp.koleo_weight * scale), 1.0)      # (ds[:V]: the leading rows, contiguous)
+            dcls = self._head_backward(self.student.head, saved, ds)
             ops.put_rows_(dfeats, 0, dcls)                                                                            # row 0 (CLS)
             roots, grads = [s_feats], [dfeats]
             if l_feats is not None:

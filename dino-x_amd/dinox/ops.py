@@ -1393,15 +1393,9 @@ class GramLossFn(torch.autograd.Function):
         return d * g, None
 
 
-def koleo_fwd(x: Tensor, eps: float = 1e-8, group=None):
-    """KoLeo regulariser on the student head output (reference scripts/phase5_big_run.py:742-773, applied at :1764-1766):
-    -mean_i log(min_{j != i} ||x^_i - x^_j|| + eps) with x^ = F.normalize(x).  fp32 in both modes, like cdist under autocast.
-    Returns (loss[1], saved) -- no autograd, no framework kernel; koleo_bwd(saved, gscale) gives d(gscale * loss)/dx.
-
-    Data parallel (``group`` with more than one rank): the neighbour of a row is searched over the GLOBAL batch, as the
-    single-process reference would at that batch size.  Two all-gathers (unit rows; then index + distance per row) and no
-    gradient collective: a row's gradient needs its own pair and the pairs that chose it, all of which are gathered data.
-    The value returned is this rank's mean over its own rows, so the mean over ranks is the global loss."""
+def koleo_begin(x: Tensor, group=None):
+    """First half of koleo_fwd: normalise the rows and -- under data parallelism -- START the all-gather of the unit rows (V x out_dim fp32 per
+    rank, 134 MB at 8 x 512 x 8192) without waiting for it, so that the caller can run independent work (the Gram loss) under the transfer."""
     import torch.distributed as dist
     _need_cuda(x)
     x = _c(x.float())
@@ -1414,12 +1408,24 @@ def koleo_fwd(x: Tensor, eps: float = 1e-8, group=None):
     f = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
     xh, norm, sq = f(V, D), f(V), f(V)
     check(lib.dinox_koleo_normalize(_p(x), _p(xh), _p(norm), _p(sq), V, D, 1e-12, _stream()), "dinox_koleo_normalize")
+    works = []
     if gather:
         xh_all, sq_all = f(world * V, D), f(world * V)
-        dist.all_gather_into_tensor(xh_all, xh, group=group)
-        dist.all_gather_into_tensor(sq_all, sq, group=group)
+        works.append(dist.all_gather_into_tensor(xh_all, xh, group=group, async_op=True))
+        works.append(dist.all_gather_into_tensor(sq_all, sq, group=group, async_op=True))
     else:
         xh_all, sq_all = xh, sq
+    return (xh, xh_all, sq_all, norm, works, group, gather, world, rank, V, D)
+
+
+def koleo_end(state, eps: float = 1e-8):
+    """Second half: wait for the gathered rows, nearest neighbours over the global batch, the loss.  Returns (loss[1], saved)."""
+    import torch.distributed as dist
+    xh, xh_all, sq_all, norm, works, group, gather, world, rank, V, D = state
+    for w in works:
+        w.wait()
+    dev = xh.device
+    f = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
     Vg, row0 = world * V, rank * V
     G = gemm_nt_f32_splitk(xh, xh_all)                                  # [V, Vg] inner products, exact-fp32 MFMA, reduction split over the chip
     idx = torch.empty(V, dtype=torch.int32, device=dev)
@@ -1435,6 +1441,19 @@ def koleo_fwd(x: Tensor, eps: float = 1e-8, group=None):
     loss = f(1)
     check(lib.dinox_koleo_loss(_p(dmin), V, eps, _p(loss), _stream()), "dinox_koleo_loss")
     return loss, (xh_all, idx_all, d_all, norm, (row0, V, Vg, D), eps)
+
+
+def koleo_fwd(x: Tensor, eps: float = 1e-8, group=None):
+    """KoLeo regulariser on the student head output (reference scripts/phase5_big_run.py:742-773, applied at :1764-1766):
+    -mean_i log(min_{j != i} ||x^_i - x^_j|| + eps) with x^ = F.normalize(x).  fp32 in both modes, like cdist under autocast.
+    Returns (loss[1], saved) -- no autograd, no framework kernel; koleo_bwd(saved, gscale) gives d(gscale * loss)/dx.
+
+    Data parallel (``group`` with more than one rank): the neighbour of a row is searched over the GLOBAL batch, as the
+    single-process reference would at that batch size.  Two all-gathers (unit rows; then index + distance per row) and no
+    gradient collective: a row's gradient needs its own pair and the pairs that chose it, all of which are gathered data.
+    The value returned is this rank's mean over its own rows, so the mean over ranks is the global loss.
+    (koleo_begin / koleo_end are the two halves, for callers that have work to run under the first all-gather.)"""
+    return koleo_end(koleo_begin(x, group), eps)
 
 
 def koleo_bwd(saved, gscale: float = 1.0) -> Tensor:

@@ -249,6 +249,8 @@ def secondary(dev, note) -> dict:
              "the headline workload with DINOX_DW_STREAM=1 (weight-gradient products on a second HIP stream: faster, but overlapping kernels cannot be priced one by one, so the headline line keeps it off)"),
             ("bs256_koleo_accum4", dict(B=256, koleo=0.1, accum=4),
              "the headline workload the way the reference's production runs use it (docs/EXPERIMENTS.md): --koleo-weight 0.1, --accumulation-steps 4 (samples/s counts micro-batches)"),
+            ("bs64_fp32", dict(B=64, fp32=True),
+             "the headline model without --amp: fp32 on the exact-fp32 matrix instructions, bs 64 (python bench.py --fp32 --batch-size 64 adds the plain-PyTorch fp32 figure)"),
             ("bs64_scale_off", dict(B=64, scale_aware=False), "BASELINE configs[1]: ViT-S/16 224, bs 64, scale-aware off, 2 views/sample"),
             ("bs64_scale_off_graph", dict(B=64, scale_aware=False, graph=True), "configs[1] with the step replayed as one captured hipGraph"),
             ("multicrop_2g8l", dict(B=256, L=8), "configs[2] read literally: 2 global + 8 local 96px views/sample (extension: the reference has 2 views)"),

@@ -220,10 +220,11 @@ def gemm(A: Tensor, B: Tensor, *, transA=False, transB=False, out: Optional[Tens
         strideA=a2[0] * a2[1] if batched else 0, strideB=(b2[0] * b2[1] if (batched and B.dim() == 3) else 0),
         strideC=M * N, transA=int(transA), transB=int(transB), in_dtype=_code(A.dtype), out_dtype=_code(odt),
         epilogue=epi, alpha=alpha, bias=_p(bias), residual=_p(residual), ldr=N, aux=_p(aux), ldaux=N, colsum=_p(colsum_out), ws=None)
-    if (transA and transB and not batched and A.dtype == torch.float32 and odt == torch.float32 and K >= 4096
-            and not (epi & ~EPI_ACCUM) and ((M + 127) // 128) * ((N + 127) // 128) < 256):
-        # fp32 dW products (parity mode): [M x N] is a few dozen tiles with the whole token axis as reduction -- 36 workgroups on 256 CUs,
-        # 3-12 ms per launch.  Cut the reduction into chunks that run as ONE batched launch and meet in the fixed-order column sum.
+    if (transA and transB and not batched and odt == torch.float32 and K >= 4096 and not (epi & ~EPI_ACCUM)
+            and ((M + 127) // 128) * ((N + 127) // 128) < 256 and lib.dinox_gemm_kernel_name(C.byref(g)).decode().startswith("gemm_f32")):
+        # dW products that land on the general exact-fp32 kernel -- the whole fp32 mode, and bf16 operands whose shape the MFMA bf16 kernels
+        # do not take (patch 14: 3 x 14 x 14 = 588 columns) -- are a few dozen tiles with the whole token axis as reduction: 36-60 workgroups
+        # on 256 CUs, 3-12 ms per launch.  Cut the reduction into chunks that run as ONE batched launch and meet in the fixed-order column sum.
         tiles = ((M + 127) // 128) * ((N + 127) // 128)
         splits = max(1, min(K // 1024, 1024 // tiles))
         while splits > 1 and K % splits:
@@ -232,14 +233,14 @@ def gemm(A: Tensor, B: Tensor, *, transA=False, transB=False, out: Optional[Tens
             kc = K // splits
             part = torch.empty((splits, M, N), dtype=torch.float32, device=A.device)
             g2 = GemmArgs(A=_p(A), B=_p(B), C=_p(part), M=M, N=N, K=kc, lda=a2[1], ldb=b2[1], ldc=N, batch=splits, strideA=kc * a2[1],
-                          strideB=kc * b2[1], strideC=M * N, transA=1, transB=1, in_dtype=F32, out_dtype=F32, epilogue=0, alpha=alpha,
+                          strideB=kc * b2[1], strideC=M * N, transA=1, transB=1, in_dtype=_code(A.dtype), out_dtype=F32, epilogue=0, alpha=alpha,
                           bias=None, residual=None, ldr=N, aux=None, ldaux=N, colsum=None, ws=None)
             if TRACE_KERNELS is not None:
                 TRACE_KERNELS.append(lib.dinox_gemm_kernel_name(C.byref(g2)).decode())
             check(lib.dinox_gemm(C.byref(g2), _stream()), "dinox_gemm")
             colsum(part.view(splits, M * N), out=out.view(-1), accumulate=accumulate)
             if colsum_out is not None:                       # A is stored [K][M]: its column sums are the bias gradient
-                check(lib.dinox_colsum(_p(A), _p(colsum_out), K, M, a2[1], F32, int(accumulate), _stream()), "dinox_colsum")
+                check(lib.dinox_colsum(_p(A), _p(colsum_out), K, M, a2[1], _code(A.dtype), int(accumulate), _stream()), "dinox_colsum")
             return out
     if transA and transB and not batched and A.dtype == torch.bfloat16 and not _TN_ATOMICS:
         need = lib.dinox_gemm_ws_bytes(C.byref(g))       # split-K dW product: deterministic two-stage reduction through a workspace

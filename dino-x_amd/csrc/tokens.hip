@@ -231,6 +231,42 @@ static unsigned grid_for(int64_t total) {
 
 using namespace dinox;
 
+// Rows of `ld` >= 3 p^2 elements, the tail zero-filled: 3 x 14 x 14 = 588 columns are no multiple of 8, so the MFMA bf16 products
+// do not take the plain matrix; padded to 640 they do (the padded weight columns are zero as well).
+template <int DT>
+__global__ __launch_bounds__(256) void unfold_ld_kernel(const float* __restrict__ x, void* __restrict__ u, int V, int H, int W, int p, int ld) {
+  const int g = W / p, gh = H / p;
+  const int Kd = 3 * p * p;
+  const int64_t total = (int64_t)V * gh * g * ld;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(idx % ld);
+    const int64_t row = idx / ld;
+    float val = 0.f;
+    if (k < Kd) {
+      const int gx = (int)(row % g);
+      const int gy = (int)((row / g) % gh);
+      const int64_t v = row / ((int64_t)g * gh);
+      const int px = k % p, py = (k / p) % p, c = k / (p * p);
+      val = x[((v * 3 + c) * H + (gy * p + py)) * (int64_t)W + gx * p + px];
+    }
+    elem<DT>::st(u, idx, val);
+  }
+}
+
+extern "C" int dinox_patch_unfold_ld(const float* x, void* u, int V, int H, int W, int patch, int ld, int out_dtype, void* stream) {
+  DX_REQUIRE(x && u, DINOX_EINVAL, "patch_unfold_ld: null pointer");
+  DX_REQUIRE(V > 0 && H > 0 && W > 0 && patch > 0 && H % patch == 0 && W % patch == 0 && ld >= 3 * patch * patch, DINOX_EINVAL,
+             "patch_unfold_ld: V=%d H=%d W=%d patch=%d ld=%d", V, H, W, patch, ld);
+  DX_REQUIRE(out_dtype == DINOX_F32 || out_dtype == DINOX_BF16, DINOX_EINVAL, "patch_unfold_ld: dtype %d", out_dtype);
+  const int64_t total = (int64_t)V * (H / patch) * (W / patch) * ld;
+  hipStream_t st = as_stream(stream);
+  if (out_dtype == DINOX_F32)
+    hipLaunchKernelGGL((unfold_ld_kernel<DINOX_F32>), dim3(grid_for(total)), dim3(256), 0, st, x, u, V, H, W, patch, ld);
+  else
+    hipLaunchKernelGGL((unfold_ld_kernel<DINOX_BF16>), dim3(grid_for(total)), dim3(256), 0, st, x, u, V, H, W, patch, ld);
+  return check_launch("patch_unfold_ld");
+}
+
 extern "C" int dinox_patch_unfold(const float* x, void* u, int V, int H, int W, int patch, int out_dtype, void* stream) {
   DX_REQUIRE(x && u, DINOX_EINVAL, "patch_unfold: null pointer");
   DX_REQUIRE(V > 0 && H > 0 && W > 0 && patch > 0 && H % patch == 0 && W % patch == 0, DINOX_EINVAL,

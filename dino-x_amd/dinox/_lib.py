@@ -53,6 +53,7 @@ SIGNATURES = {
     "dinox_attention_bwd_ws_bytes": (i64, [i32, i32, i32]),
     "dinox_attention_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "dinox_patch_unfold": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "dinox_patch_unfold_ld": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "dinox_tokens_fwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "dinox_tokens_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "dinox_scale_embed_fwd": (i32, [vp] * 12 + [i32, i32, i32, f32, vp]),

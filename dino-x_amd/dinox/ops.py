@@ -401,10 +401,12 @@ class _WeightCache:
 
     def __init__(self) -> None:
         self.d: dict = {}
+        self.extra: dict = {}          # other per-step images of a weight (the zero-padded patch-embedding operand), same lifetime
         self.shadows: list = []
 
     def clear(self) -> None:
         self.d.clear()
+        self.extra.clear()
 
     def get(self, w: Tensor, transposed: bool) -> Tensor:
         for sh in self.shadows:
@@ -1063,8 +1065,28 @@ def unfold_share():
             _unfold_share.entries = []
 
 
+def patch_cols(patch: int, dt: torch.dtype) -> int:
+    """Columns of the unfolded patch matrix: 3 p^2, rounded up to a multiple of 64 in the bf16 mode when 3 p^2 is no multiple of 8 (patch
+    14: 588 -> 640) -- the MFMA bf16 products take no other shape; the tail columns are zeros on both operands."""
+    k = 3 * patch * patch
+    return k if (dt != torch.bfloat16 or k % 8 == 0) else (k + 63) // 64 * 64
+
+
+def padded_patch_weight(pw: Tensor, dt: torch.dtype, cols: int) -> Tensor:
+    """The patch-embedding weight [D, 3 p^2] as a [D, cols] operand with zero tail columns (built once per optimiser step)."""
+    key = (id(pw), "padK", cols)
+    hit = weight_cache.extra.get(key)
+    if hit is not None and hit[0]() is pw and hit[2] == (pw.data_ptr(), pw._version):
+        return hit[1]
+    w2 = pw.detach().reshape(pw.shape[0], -1)
+    out = torch.zeros((w2.shape[0], cols), dtype=dt, device=pw.device)
+    out[:, :w2.shape[1]].copy_(w2)
+    weight_cache.extra[key] = (weakref.ref(pw), out, (pw.data_ptr(), pw._version))
+    return out
+
+
 def patch_unfold(x: Tensor, patch: int, dt: torch.dtype) -> Tensor:
-    """[V,3,H,W] fp32 -> [V*P, 3*p*p] in dt (shared between student and teacher inside ``unfold_share()`` only)."""
+    """[V,3,H,W] fp32 -> [V*P, patch_cols(patch, dt)] in dt (shared between student and teacher inside ``unfold_share()`` only)."""
     _need_cuda(x)
     sharing = _unfold_share.depth > 0
     if sharing:
@@ -1077,8 +1099,12 @@ def patch_unfold(x: Tensor, patch: int, dt: torch.dtype) -> Tensor:
         x = x.float()
     V, Cn, H, W = x.shape
     assert Cn == 3, "2.5D slice stacks have 3 channels"
-    u = torch.empty((V * (H // patch) * (W // patch), 3 * patch * patch), dtype=dt, device=x.device)
-    check(lib.dinox_patch_unfold(_p(x), _p(u), V, H, W, patch, _code(dt), _stream()), "dinox_patch_unfold")
+    cols = patch_cols(patch, dt)
+    u = torch.empty((V * (H // patch) * (W // patch), cols), dtype=dt, device=x.device)
+    if cols == 3 * patch * patch:
+        check(lib.dinox_patch_unfold(_p(x), _p(u), V, H, W, patch, _code(dt), _stream()), "dinox_patch_unfold")
+    else:
+        check(lib.dinox_patch_unfold_ld(_p(x), _p(u), V, H, W, patch, cols, _code(dt), _stream()), "dinox_patch_unfold_ld")
     if sharing:
         _unfold_share.put(x0, patch, dt, u)
     return u
@@ -1095,7 +1121,9 @@ class TokensFn(torch.autograd.Function):
         D = pw.shape[0]
         P = u.shape[0] // V
         R = 0 if regs is None else regs.shape[1]
-        patches = gemm(u, weight_operand(pw, dt), bias=pb, out_dtype=dt)
+        K0 = 3 * patch * patch
+        wop = weight_operand(pw, dt) if u.shape[1] == K0 else padded_patch_weight(pw, dt, u.shape[1])
+        patches = gemm(u, wop, bias=pb, out_dtype=dt)
         tokens = torch.empty((V, 1 + P + R, D), dtype=torch.float32, device=x.device)
         sc = None if scale is None else _c(scale).reshape(V, D)
         check(lib.dinox_tokens_fwd(_p(patches), _p(_c(cls)), _p(_c(pos)), _p(None if regs is None else _c(regs)), _p(sc), _p(tokens),
@@ -1120,7 +1148,24 @@ class TokensFn(torch.autograd.Function):
         dscale = torch.empty((V, 1, D), dtype=torch.float32, device=dev) if ctx.has_scale else None
         check(lib.dinox_tokens_bwd(_p(dtok), _p(dpatches), _p(dcls), _p(dpos), _p(dregs), _p(dscale), V, P, R, D, _code(dt), _stream()),
               "dinox_tokens_bwd")
-        dw, db = weight_grad(dpatches, u, pw, pb, pb is not None)
+        K0 = pw[0].numel()
+        if u.shape[1] == K0:
+            dw, db = weight_grad(dpatches, u, pw, pb, pb is not None)
+        else:
+            # padded operand (patch 14): the product gives [D, cols]; its first 3 p^2 columns are the gradient.  One strided add per step
+            # into the arena (the only place of a step where a framework kernel does arithmetic, and only at such patch sizes).
+            dbt = torch.empty(D, dtype=torch.float32, device=dev) if pb is not None else None
+            dwp = gemm(dpatches, u, transA=True, transB=True, out_dtype=torch.float32, colsum_out=dbt)
+            sw, sb = grad_sink.lookup(pw), (grad_sink.lookup(pb) if pb is not None else None)
+            if sw is not None and (pb is None or sb is not None):
+                sw[1].grad.view(D, K0).add_(dwp[:, :K0])
+                grad_sink.ready(sw)
+                if pb is not None:
+                    axpy_(sb[1].grad.view(-1), dbt, 1.0)
+                    grad_sink.ready(sb)
+                dw = db = None
+            else:
+                dw, db = dwp[:, :K0].reshape(pw.shape).contiguous(), dbt
         cls, pos, regs = ctx.small
         return None, dw, db, small_grad(cls, dcls), small_grad(pos, dpos), small_grad(regs, dregs), dscale, None
 

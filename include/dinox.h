@@ -178,6 +178,9 @@ int dinox_attention_bwd(const void* d_o, const void* qkv, const void* o, const f
  *               dscale[v] = sum over the 1+P body tokens (NULL when not scale-aware).
  * ------------------------------------------------------------------------------------------ */
 int dinox_patch_unfold(const float* x, void* u, int V, int H, int W, int patch, int out_dtype, void* stream);
+/* The same with rows of ld >= 3 p^2 elements, the tail zero-filled (patch sizes whose 3 p^2 is no multiple of 8: the operand of the
+ * MFMA bf16 products is padded; the weight operand gets zero columns to match). */
+int dinox_patch_unfold_ld(const float* x, void* u, int V, int H, int W, int patch, int ld, int out_dtype, void* stream);
 int dinox_tokens_fwd(const void* patches, const float* cls, const float* pos, const float* registers,
                      const float* scale, float* tokens, int V, int P, int R, int D, int patches_dtype,
                      void* stream);

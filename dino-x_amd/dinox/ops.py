@@ -535,6 +535,13 @@ def _use_f32_products(qkv: Tensor, N: int, d: int) -> bool:
     return qkv.dtype == torch.float32 and not _ATTN_F32_REF and N >= 32 and qkv.shape[0] * N >= 4096
 
 
+def _bf16_attention_needs_products(qkv: Tensor, N: int, d: int, fwd: bool) -> bool:
+    """bf16 mode, a shape outside the MFMA attention kernels (head size 64; <= 288 tokens forward, <= 544 backward), big enough to matter."""
+    if qkv.dtype != torch.bfloat16 or _ATTN_F32_REF or N < 32 or qkv.shape[0] * N < 4096:
+        return False
+    return d != 64 or N > (288 if fwd else 544)
+
+
 def _attention_fwd_f32_products(qkv: Tensor, heads: int, o: Tensor, lse: Tensor) -> None:
     """softmax(Q K^T / sqrt(d)) V per head as S = scale Q K^T (NT), softmax rows, O = P V -- operands addressed inside the packed qkv
     [B, N, 3, heads, d] and o [B, N, heads, d] by leading dimensions and batch strides."""
@@ -586,6 +593,13 @@ def attention_fwd(qkv: Tensor, heads: int):
     if _use_f32_products(qkv, N, d):
         _attention_fwd_f32_products(qkv, heads, o, lse)
         return o, lse
+    if _bf16_attention_needs_products(qkv, N, d, fwd=True):
+        # head sizes / sequence lengths the MFMA attention kernels do not take (ViT-g: 88 per head; > 288 tokens): the exact-fp32 product
+        # form on a float copy instead of the per-lane reference kernels (which are two orders of magnitude slower at these sizes)
+        q32 = qkv.float()
+        o32 = torch.empty((B, N, Cc), dtype=torch.float32, device=qkv.device)
+        _attention_fwd_f32_products(q32, heads, o32, lse)
+        return o32.to(qkv.dtype), lse
     check(lib.dinox_attention_fwd(_p(qkv), _p(o), _p(lse), B, N, heads, d, _code(qkv.dtype), _stream()), "dinox_attention_fwd")
     return o, lse
 
@@ -598,6 +612,10 @@ def attention_bwd(do: Tensor, qkv: Tensor, o: Tensor, lse: Tensor, heads: int) -
     if _use_f32_products(qkv, N, d):
         _attention_bwd_f32_products(_c(do), _c(qkv), o, lse, heads, dqkv)
         return dqkv
+    if _bf16_attention_needs_products(qkv, N, d, fwd=False):
+        d32 = torch.empty(qkv.shape, dtype=torch.float32, device=qkv.device)
+        _attention_bwd_f32_products(_c(do).float(), _c(qkv).float(), o, lse, heads, d32)
+        return d32.to(qkv.dtype)
     ws = torch.empty(lib.dinox_attention_bwd_ws_bytes(B, N, heads), dtype=torch.uint8, device=qkv.device)
     check(lib.dinox_attention_bwd(_p(do), _p(qkv), _p(o), _p(lse), _p(dqkv), _p(ws), B, N, heads, d, _code(qkv.dtype), _stream()),
           "dinox_attention_bwd")

@@ -1617,6 +1617,22 @@ def test_fp32_mode_fast_paths_equal_the_reference_kernels(dx):
     close(o1, o0, 1e-5, 1e-6, "fp32 attention o")
     close(l1, l0, 1e-6, 1e-6, "fp32 attention lse")
     close(d1, d0, 2e-5, 1e-6, "fp32 attention dqkv")
+    # (a') bf16 mode, a head size the MFMA attention kernels do not take (ViT-g: 88): the product form on a float copy
+    Bg, Ng, Hg, dg = 48, 100, 4, 88
+    qb = (torch.randn(Bg, Ng, 3 * Hg * dg, device="cuda", generator=g) * 0.5).bfloat16()
+    dob = (torch.randn(Bg, Ng, Hg * dg, device="cuda", generator=g) * 0.1).bfloat16()
+    assert ops._bf16_attention_needs_products(qb, Ng, dg, fwd=True)
+    ob, lb = ops.attention_fwd(qb, Hg)
+    db_ = ops.attention_bwd(dob, qb, ob, lb, Hg)
+    ops._ATTN_F32_REF = True
+    try:
+        orf, lrf = ops.attention_fwd(qb, Hg)
+        drf = ops.attention_bwd(dob, qb, orf, lrf, Hg)
+    finally:
+        ops._ATTN_F32_REF = False
+    assert ob.dtype == torch.bfloat16 and db_.dtype == torch.bfloat16
+    assert rel_l2(ob.float(), orf.float()) < 6e-3 and rel_l2(db_.float(), drf.float()) < 1e-2
+    close(lb, lrf, 1e-4, 1e-4, "lse (head size 88)")
     # (b) dW = dy^T x with K = 16384 tokens, accumulated into an existing gradient, with the bias gradient
     K, M, Nn = 16384, 384, 256
     dy, x = torch.randn(K, M, device="cuda", generator=g), torch.randn(K, Nn, device="cuda", generator=g)

@@ -359,6 +359,10 @@ def main() -> None:
                         all_gemm_kernels={k: {"launches": v["launches"], "ms": round(v["ms"], 3),
                                               "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
                                               "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)} for k, v in kernels.items()})
+        if roof.get("kernel") == "gemm_bf16_nt_areg":
+            roof["family_note"] = ("since round 2 the 24 proj launches per step (the family's shortest and most bandwidth-efficient: 396 MB in 90 us) run in "
+                                   "gemm_bf16_rowln with the LayerNorm behind them; 77 launches are left here (qkv, fc1, GELU' product, dX of proj), so the "
+                                   "family average moved from 131 us / 0.387 to ~144 us / ~0.355 with every shape's time unchanged (DESIGN.md section 4)")
         # HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE and, in a
         # separate run, WRITE_SIZE of this same command; FETCH doubled per the gfx950 correction) -- bench.py cannot
         # run the profiler on itself, so the figure is read from profiles/ and is null when that file is absent.

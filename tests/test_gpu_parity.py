@@ -1633,6 +1633,19 @@ def test_fp32_mode_fast_paths_equal_the_reference_kernels(dx):
     assert ob.dtype == torch.bfloat16 and db_.dtype == torch.bfloat16
     assert rel_l2(ob.float(), orf.float()) < 6e-3 and rel_l2(db_.float(), drf.float()) < 1e-2
     close(lb, lrf, 1e-4, 1e-4, "lse (head size 88)")
+    # (a'') bf16 mode, head size 64 but 600 tokens (> 288 forward, > 544 backward: outside the MFMA kernels)
+    ql = (torch.randn(8, 600, 3 * 2 * 64, device="cuda", generator=g) * 0.5).bfloat16()
+    dol = (torch.randn(8, 600, 2 * 64, device="cuda", generator=g) * 0.1).bfloat16()
+    assert ops._bf16_attention_needs_products(ql, 600, 64, fwd=True) and ops._bf16_attention_needs_products(ql, 600, 64, fwd=False)
+    ol, ll = ops.attention_fwd(ql, 2)
+    dl = ops.attention_bwd(dol, ql, ol, ll, 2)
+    ops._ATTN_F32_REF = True
+    try:
+        orl, lrl = ops.attention_fwd(ql, 2)
+        drl = ops.attention_bwd(dol, ql, orl, lrl, 2)
+    finally:
+        ops._ATTN_F32_REF = False
+    assert rel_l2(ol.float(), orl.float()) < 6e-3 and rel_l2(dl.float(), drl.float()) < 1e-2
     # (b) dW = dy^T x with K = 16384 tokens, accumulated into an existing gradient, with the bias gradient
     K, M, Nn = 16384, 384, 256
     dy, x = torch.randn(K, M, device="cuda", generator=g), torch.randn(K, Nn, device="cuda", generator=g)

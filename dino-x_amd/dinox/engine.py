@@ -152,7 +152,9 @@ class TrainEngine:
             self._eager_steps += 1
             return self._step_eager(*inputs)
         lr = get_lr(self.step_count, hp.max_steps, hp.warmup_steps, hp.lr, hp.min_lr)
-        self._hyper_host.copy_(torch.tensor(ops.adamw_hyper(lr, hp.beta1, hp.beta2, self.opt_steps + 1), dtype=torch.float32))
+        # a FRESH page-locked staging tensor per step (the host allocator recycles it only after the copy has run): with one reused
+        # buffer a host running two steps ahead would overwrite the scalars of a copy that is still queued
+        self._hyper_host = torch.tensor(ops.adamw_hyper(lr, hp.beta1, hp.beta2, self.opt_steps + 1), dtype=torch.float32).pin_memory()
         self._hyper_dev.copy_(self._hyper_host, non_blocking=True)
         if self._graph is None:
             self._static = [None if t is None else t.clone() for t in inputs]

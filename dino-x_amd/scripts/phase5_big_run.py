@@ -578,6 +578,9 @@ def build_parser() -> argparse.ArgumentParser:
                     help="Multi-crop extension (the reference trains on 2 global views): L extra student-only local views per sample, "
                          "crop scale 0.05-0.3; needs --gpu-views")
     ap.add_argument("--local-size", type=int, default=96, help="Side of the local views (a multiple of the patch size)")
+    ap.add_argument("--hip-graph", action="store_true",
+                    help="Replay the whole optimiser step as one captured hipGraph after two eager steps (extension; single GPU, "
+                         "--accumulation-steps 1): for small batches, where launching ~300 kernels per step costs more than running them")
     ap.add_argument("--gpu-views", action="store_true",
                     help="Build both views on the GPU (HU decode, window, antialiased bicubic RandomResizedCrop, flip, normalise in one "
                          "kernel); DataLoader workers then only decode PNGs")
@@ -755,8 +758,10 @@ def main(argv=None) -> None:
                          weight_decay=args.weight_decay, ema=args.ema, teacher_temp=args.teacher_temp, student_temp=args.student_temp,
                          center_momentum=args.center_momentum, gram_weight=args.gram_weight,
                          koleo_weight=args.koleo_weight)
+    if args.hip_graph and (world > 1 or args.accumulation_steps != 1 or args.local_crops):
+        raise SystemExit("--hip-graph: single GPU, --accumulation-steps 1 and no --local-crops (the captured step has one fixed batch layout)")
     eng = TrainEngine(student, teacher, model_cfg.out_dim, hp, amp_dtype=torch.bfloat16 if args.amp else None,
-                      accumulation_steps=args.accumulation_steps)
+                      accumulation_steps=args.accumulation_steps, use_graph=bool(args.hip_graph))
     start_step = 0
     if resume_from:
         say(f"resume=true checkpoint={resume_from}")

@@ -549,10 +549,47 @@ bool gemm_bf16_nt_glds_ok(const GemmParams& p);
 int launch_gemm_bf16_nt_glds(const GemmParams& p, hipStream_t st);
 bool gemm_bf16_nt_areg_ok(const GemmParams& p);
 int launch_gemm_bf16_nt_areg(const GemmParams& p, hipStream_t st);
+bool gemm_bf16_nt_pp_ok(const GemmParams& p);                                                   // gemm_bf16_pp.hip
+int launch_gemm_bf16_nt_pp(const GemmParams& p, hipStream_t st);
+bool gemm_bf16_nt_pp128_ok(const GemmParams& p);                                                // gemm_bf16_pp128.hip
+int launch_gemm_bf16_nt_pp128(const GemmParams& p, hipStream_t st);
+
+// Which NT products take the persistent ping-pong kernels (gemm_bf16_pp.hip: 256 x 256 tiles, gemm_bf16_pp128.hip: 256 x 128), and which
+// of the two.  DINOX_NT_PP (read per call, so one process can A/B and the tests can force small shapes onto them): 0 = never; 1 = every
+// product inside the envelope, tile width by shape; 2 / 3 = every product on the 128-wide / 256-wide tiles; unset = the measured policy.
+static const char* nt_pp_choice(const GemmParams& p) {
+  if (p.transA || p.transB) return nullptr;
+  const char* e = getenv("DINOX_NT_PP");
+  const int mode = e ? atoi(e) : -1;
+  if (mode == 0) return nullptr;
+  const bool ok256 = gemm_bf16_nt_pp_ok(p), ok128 = gemm_bf16_nt_pp128_ok(p);
+  if (mode == 2) return ok128 ? "gemm_bf16_nt_pp128" : nullptr;
+  if (mode == 3) return ok256 ? "gemm_bf16_nt_pp" : nullptr;
+  // a narrow last column tile wastes matrix work on the 256-wide form: N = 384 is 1.5 tiles (and 804 tiles = 3.14 rounds on 256 CUs)
+  const int64_t rem = p.N % 256;
+  const bool narrow = p.N < 1024 && rem != 0 && rem <= 128;
+  const char* pick = narrow ? (ok128 ? "gemm_bf16_nt_pp128" : nullptr) : (ok256 ? "gemm_bf16_nt_pp" : nullptr);
+  if (mode >= 1 || !pick) return pick;
+  // Measured policy (tools/pp_check.py, MI355X, old = gemm_bf16_nt_areg / _glds; M = 102 912 / 51 456 / 25 728 tokens):
+  //   256-wide: qkv 140 -> 104-112 us, plain K 384 N 1536 164 -> 125-131, GELU' product 186 -> 172-176 (x0.9 at every M); ViT-L qkv 425 -> 291,
+  //             fc1 651 -> 480, fc2 525 -> 452 us.  The GELU epilogue at K = 384 is the exception: it is bound by its ~50 VALU cycles per
+  //             element either way (fc1 206 vs 203-214 us), so it stays on the register-prefetch kernel until K >= 768;
+  //   128-wide: dX K 1152 123 -> 92-96, dX K 1536 160 -> 138, fc2 196 -> 176 at every M; the K = 384 products only on a full chip
+  //             (dX of proj 55 -> 45 us at M = 102 912, 28 vs 30 at 51 456) and not with the fp32 residual (proj: 83 vs 93 us).
+  // Small problems (less than one round of tiles) keep the 128 x 128 kernels, whose tiles are four times as many.
+  const int64_t units = ceil_div(p.M, (int64_t)256) * ceil_div(p.N, (int64_t)(narrow ? 128 : 256));
+  if (narrow) {
+    if (p.K >= 768) return units >= 192 ? pick : nullptr;
+    return (units >= 1024 && !(p.epilogue & DINOX_EPI_RESIDUAL)) ? pick : nullptr;
+  }
+  if ((p.epilogue & DINOX_EPI_GELU) && p.K < 768) return nullptr;
+  return units >= 192 ? pick : nullptr;
+}
 
 const char* gemm_bf16_variant(const GemmParams& p) {
   if (p.in_dtype != DINOX_BF16) return nullptr;
   if (!aligned16(p.A) || !aligned16(p.B) || (p.lda & 7) || (p.ldb & 7) || (p.strideA & 7) || (p.strideB & 7)) return nullptr;
+  if (const char* pp = nt_pp_choice(p)) return pp;
   if (gemm_bf16_nt_glds_ok(p)) {
     // Short reductions (K = 384: qkv, proj, fc1, GELU' products of ViT-S) take the form that prefetches the token operand through
     // registers (gemm_bf16_areg.hip): -7 .. -12 % per launch, where the first loads' latency is a large part of a 12-step tile.
@@ -598,7 +635,7 @@ int64_t gemm_bf16_ws_bytes(const GemmParams& p) {
 int launch_gemm_bf16(const GemmParams& p, hipStream_t st) {
   const char* v = gemm_bf16_variant(p);
   if (!v) return DINOX_EUNSUPPORTED;
-  if (v[10] == 'n' && v[12] == '_') return v[13] == 'a' ? launch_gemm_bf16_nt_areg(p, st) : launch_gemm_bf16_nt_glds(p, st);
+  if (v[10] == 'n' && v[12] == '_') return v[13] == 'p' ? (v[15] == '1' ? launch_gemm_bf16_nt_pp128(p, st) : launch_gemm_bf16_nt_pp(p, st)) : v[13] == 'a' ? launch_gemm_bf16_nt_areg(p, st) : launch_gemm_bf16_nt_glds(p, st);
   const int tiles_m = (int)ceil_div(p.M, GB_BM), tiles_n = (int)ceil_div(p.N, GB_BN);
   const int64_t ntile = (int64_t)tiles_m * tiles_n;
   if (ntile > 0x7fffffff || p.batch > 65535) return DINOX_EUNSUPPORTED;

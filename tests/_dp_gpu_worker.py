@@ -18,12 +18,15 @@ dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
 accum = int(os.environ.get("DINOX_TEST_ACCUM") or 1)
 ckpt = bool(os.environ.get("DINOX_TEST_GRAD_CKPT"))
-kw = dict(img_size=56, patch=14, dim=64, depth=2, heads=2, num_registers=4, scale_aware=True, use_grad_checkpoint=ckpt)
+crops = int(os.environ.get("DINOX_TEST_LOCAL_CROPS") or 0)        # L local 28-px crops per sample (multi-crop extension)
+scale_aware = os.environ.get("DINOX_TEST_SCALE_AWARE", "1") != "0"
+kw = dict(img_size=56, patch=14, dim=64, depth=2, heads=2, num_registers=4, scale_aware=scale_aware, use_grad_checkpoint=ckpt)
 torch.manual_seed(100 + rank)                      # different init per rank: the engine must broadcast rank 0's weights
 if world == 1:
     torch.manual_seed(100)
 student = arch.DinoStudentTeacher(arch.PatchViT(**kw), 256)
-torch.nn.init.xavier_uniform_(student.backbone.scale_embed.mlp[2].weight)
+if scale_aware:
+    torch.nn.init.xavier_uniform_(student.backbone.scale_embed.mlp[2].weight)
 teacher = arch.DinoStudentTeacher(arch.PatchViT(**kw), 256)
 teacher.load_state_dict(student.state_dict())
 eng = TrainEngine(student.to(dev), teacher.to(dev), 256, StepHyperParams(lr=1e-3, warmup_steps=1, max_steps=10, ema=0.99, koleo_weight=0.1),
@@ -38,9 +41,14 @@ v1, v2 = torch.randn(B, 3, 56, 56, generator=g), torch.randn(B, 3, 56, 56, gener
 sp = torch.rand(B, 3, generator=g) * 2 + 0.4
 lo, hi = shard_range(B, rank, world)
 batch = torch.cat([v1[lo:hi], v2[lo:hi]], 0).to(dev)
-sp2 = torch.cat([sp[lo:hi], sp[lo:hi]], 0).to(dev)
+sp2 = torch.cat([sp[lo:hi], sp[lo:hi]], 0).to(dev) if scale_aware else None
+loc = lsp = None
+if crops:                                           # view-major local crops of this rank's samples
+    lv = torch.randn(crops, B, 3, 28, 28, generator=g)
+    loc = lv[:, lo:hi].reshape(-1, 3, 28, 28).to(dev)
+    lsp = sp[lo:hi].repeat(crops, 1).to(dev) if scale_aware else None
 for _ in range(2 * accum):                          # two optimiser steps
-    eng.step(batch, sp2)
+    eng.step(batch, sp2, loc, lsp)
 sc = eng.scalars()
 torch.save({"flat_p": eng.flat_p.cpu(), "center": eng.center.cpu(), "loss": sc["loss"], "grad_norm": sc["grad_norm"],
             "buckets": len(eng.bucketer.buckets), "fired_in_backward": eng.bucketer.fired_in_backward}, sys.argv[1])

@@ -122,6 +122,34 @@ def dp_oracle(rank, world, port, out):
     dist.destroy_process_group()
 
 
+def rank_death(rank, world, port, out):
+    """Rank 1 dies in the middle of a step (after arming, before its gradients exist); rank 0 must come out of finish() with an error
+    within the process group's time-out instead of waiting for ever."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      DINOX_DIST_BACKEND="gloo", DINOX_DIST_TIMEOUT_S="8")
+    torch.set_num_threads(2)
+    from dinox.dp import GradBucketer, init_process_group, shard_range
+    from dinox.engine import flatten_parameters
+    init_process_group()
+    model = toy()
+    flat_p, params, offs = flatten_parameters(model)
+    flat_g = torch.zeros_like(flat_p)
+    for p, o in zip(params, offs):
+        p.grad = flat_g[o:o + p.numel()].view(p.shape)
+    bk = GradBucketer(params, offs, flat_g, bucket_bytes=160)
+    X, Y = toy_data()
+    lo, hi = shard_range(8, rank, world)
+    bk.arm()
+    ((model(X[lo:hi]) - Y[lo:hi]) ** 2).mean().backward()
+    bk.finish()                                                      # step 1: both ranks alive
+    bk.arm()
+    if rank == 1:
+        os._exit(3)                                                  # no clean-up, no goodbye: what a crashed rank looks like
+    ((model(X[lo:hi]) - Y[lo:hi]) ** 2).mean().backward()
+    bk.finish()                                                      # must raise
+    np.savez(out, survived=1)                                        # (never reached)
+
+
 if __name__ == "__main__":
     which, rank, world, port, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
-    {"bucketer": bucketer, "bucketer_accum": bucketer_accum, "dp_oracle": dp_oracle}[which](rank, world, port, out)
+    {"bucketer": bucketer, "bucketer_accum": bucketer_accum, "dp_oracle": dp_oracle, "rank_death": rank_death}[which](rank, world, port, out)

@@ -80,6 +80,7 @@ def test_gemm_dispatch_by_shape(monkeypatch):
         return _lib.lib.dinox_gemm_kernel_name(ctypes.byref(g)).decode()
 
     monkeypatch.delenv("DINOX_NT_AREG_MAXK", raising=False)
+    monkeypatch.setenv("DINOX_NT_PP", "0")                  # the 128 x 128 kernels first (round 3's ping-pong kernels: below)
     T = 512 * 201
     assert name(T, 1152, 384, epi=EPI_BIAS) == "gemm_bf16_nt_areg"                                  # qkv
     assert name(T, 384, 384, epi=EPI_BIAS | EPI_RESIDUAL, out=F32, res=0x50000) == "gemm_bf16_nt_areg"   # proj
@@ -93,3 +94,20 @@ def test_gemm_dispatch_by_shape(monkeypatch):
     assert name(T, 384, 1536) == "gemm_bf16_nt_areg" and name(T // 2, 1024, 1024) == "gemm_bf16_nt_glds"   # K % 192 rules
     monkeypatch.setenv("DINOX_NT_AREG_MAXK", "0")
     assert name(T, 1152, 384, epi=EPI_BIAS) == "gemm_bf16_nt_glds"
+    # round 3, default policy (csrc/gemm_bf16.hip nt_pp_choice): which hot-path products go to the persistent ping-pong kernels
+    from dinox.ops import EPI_AUXGRAD
+    monkeypatch.delenv("DINOX_NT_PP", raising=False)
+    monkeypatch.delenv("DINOX_NT_AREG_MAXK", raising=False)
+    assert name(T, 1152, 384, epi=EPI_BIAS) == "gemm_bf16_nt_pp"                                                          # qkv: 256 x 256 tiles
+    assert name(T, 1536, 384, epi=EPI_BIAS | EPI_GELU | EPI_AUXGRAD, aux=0x60000) == "gemm_bf16_nt_areg"                  # fc1: VALU-bound either way
+    assert name(T, 1536, 384, epi=EPI_DGELU | EPI_AUXGRAD, aux=0x60000) == "gemm_bf16_nt_pp"                              # GELU' product
+    assert name(T, 384, 1536, epi=EPI_BIAS | EPI_RESIDUAL, out=F32, res=0x50000) == "gemm_bf16_nt_pp128"                  # fc2: 256 x 128 tiles
+    assert name(T, 384, 1152) == "gemm_bf16_nt_pp128" and name(T, 384, 1536) == "gemm_bf16_nt_pp128"                      # dX of qkv / fc1
+    assert name(T, 384, 384) == "gemm_bf16_nt_pp128" and name(T // 4, 384, 384) == "gemm_bf16_nt_areg"                    # dX of proj: a full chip only
+    assert name(T, 384, 384, epi=EPI_BIAS | EPI_RESIDUAL, out=F32, res=0x50000) == "gemm_bf16_nt_areg"                    # proj without the fused LayerNorm
+    assert name(T // 2, 4096, 1024, epi=EPI_GELU | EPI_AUXGRAD, aux=0x60000) == "gemm_bf16_nt_pp"                         # ViT-L fc1
+    assert name(T // 2, 1024, 4096, epi=EPI_RESIDUAL, out=F32, res=0x50000) == "gemm_bf16_nt_pp"                          # ViT-L fc2
+    assert name(804, 1152, 384, epi=EPI_BIAS) == "gemm_bf16_nt_areg"                                                      # less than one round of tiles
+    assert name(T, 1152, 384, epi=EPI_BIAS | EPI_GELU, aux=0x60000) == "gemm_bf16_nt_areg"                                # side tensor = pre-activation: not taken
+    monkeypatch.setenv("DINOX_NT_PP", "2")
+    assert name(804, 1152, 384, epi=EPI_BIAS) == "gemm_bf16_nt_pp128"                                                     # forced (tests)

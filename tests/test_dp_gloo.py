@@ -87,6 +87,30 @@ def test_two_rank_step_equals_global_batch_oracle(tmp_path):
     np.testing.assert_allclose(got["center"], O.center_update(st.center, t_out, hp.center_momentum).numpy(), rtol=1e-5, atol=1e-7)
 
 
+def test_a_dying_rank_takes_the_job_down(tmp_path):
+    """A rank that crashes mid-step (tests/_dp_workers.py::rank_death: os._exit between arm() and backward) must not leave its peer
+    waiting in GradBucketer.finish(): the survivor raises within the process group's time-out (dinox.dp.init_process_group,
+    DINOX_DIST_TIMEOUT_S) and exits non-zero, so a launcher (torchrun) tears the job down.  Fresh child processes only."""
+    import time
+    port, out = _free_port(), str(tmp_path / "out.npz")
+    t0 = time.time()
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_dp_workers.py"), "rank_death", str(r), "2", str(port), out],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=90)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            o, _ = p.communicate()
+            o += b"\n[killed by the test: still running after 90 s]"
+        logs.append(o.decode(errors="replace")[-1500:])
+    assert procs[1].returncode == 3, logs[1]
+    assert procs[0].returncode not in (0, None, -9), "the surviving rank did not fail:\n" + logs[0]
+    assert time.time() - t0 < 80 and not os.path.exists(out)
+    assert "gradient exchange failed" in logs[0] or "Connection" in logs[0] or "timed out" in logs[0].lower(), logs[0]
+
+
 def test_shard_range_rejects_ragged():
     from dinox.dp import shard_range
     assert shard_range(8, 1, 2) == (4, 8)

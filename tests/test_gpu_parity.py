@@ -504,21 +504,35 @@ def test_three_training_steps_golden(dx):
         assert r["gram"] == pytest.approx(float(g["grams"][step]), rel=1e-3, abs=1e-9)
         assert r["grad_norm"] == pytest.approx(float(g["grad_norms"][step]), rel=1e-3)
         assert r["lr"] == pytest.approx(float(g["lrs"][step]), rel=1e-12)
-    # Adam amplifies round-off on numerically-zero gradients to +-lr (see tests/test_oracle_golden.py);
-    # compare with an lr-scaled absolute floor: 3 steps, lr <= 1e-3.
-    sd = student.state_dict()
-    worst = 0.0
-    for k, v in sub(g, "student3").items():
-        d = (sd[k].cpu().double() - v.double()).abs().max().item()
-        worst = max(worst, d)
-        assert d <= 6.5e-3, (k, d)
-    frac_tight = np.mean([float(((sd[k].cpu().double() - v.double()).abs() <= 1e-3 * v.double().abs().max() + 1e-5).double().mean())
-                          for k, v in sub(g, "student3").items()])
-    assert frac_tight > 0.97, frac_tight
+    # Updated weights.  Adam turns a numerically-zero gradient (|g| < 1e-6: the key bias, to which softmax is invariant, and most of the
+    # scale-embed input layer) into a +-lr move whose sign is round-off; THOSE elements -- named by the oracle's own gradients of the
+    # three steps, the mask tests/test_oracle_golden.py::test_three_training_steps pins against the reference -- are compared at the
+    # scale 3 steps x lr allow.  Every other element must sit within 1e-3 of the reference's value (round 2 allowed any 3 % of the
+    # elements to be off by 6.5e-3).
+    from oracle import dinox_oracle as O
+    ocfg = O.VitCfg(out_dim=out_dim, **cfg)
+    ohp = O.HyperParams(lr=lr, min_lr=min_lr, warmup_steps=int(warm), max_steps=int(max_steps), weight_decay=wd, ema=ema, student_temp=ts,
+                        teacher_temp=tt, center_momentum=cm, gram_weight=gw)
+    ost = O.init_state(ocfg, sub(g, "init"))
+    noisy = {}
+    for step in range(3):
+        r = O.train_step(ost, t(g[f"batch{step}"]), t(g[f"spacing{step}"]), ohp)
+        for k, gr in r["grads"].items():
+            noisy[k] = noisy.get(k, torch.zeros_like(gr, dtype=torch.bool)) | (gr.abs() < 1e-6)
+    lr_sum = float(sum(float(v) for v in g["lrs"][:3]))
+    for name, have, want_sd, tol_noisy in (("student", student.state_dict(), sub(g, "student3"), 2.1 * lr_sum),
+                                           ("teacher", teacher.state_dict(), sub(g, "teacher3"), 2.1 * lr_sum * (1 - ema) * 3)):
+        n_tight = n_bad = 0
+        for k, v in want_sd.items():
+            d = (have[k].cpu().double() - v.double()).abs()
+            m = noisy[k]
+            if m.any():
+                assert float(d[m].max()) <= tol_noisy, (name, k, float(d[m].max()))
+            tight = d[~m]
+            n_tight += tight.numel()
+            n_bad += int((tight > 1e-3 * v.double().abs()[~m] + 2e-5).sum())
+        assert n_bad <= 1e-4 * n_tight, (name, n_bad, n_tight)
     close(eng.center, g["center3"], 1e-3, 1e-6, "center3")
-    tsd = teacher.state_dict()
-    for k, v in sub(g, "teacher3").items():
-        assert (tsd[k].cpu().double() - v.double()).abs().max().item() <= 2e-3, k
 
 
 def test_cpu_tensors_fail_loudly(dx):
@@ -584,19 +598,23 @@ def test_cli_train_checkpoint_resume(dx, tmp_path, capsys):
 
 
 # ------------------------------------------------------------------------------------------ data parallel on a real device
-@pytest.mark.parametrize("accum,ckpt", [(1, False), (2, False), (1, True)])
-def test_engine_data_parallel_two_ranks_match_single_process(dx, tmp_path, accum, ckpt):
+@pytest.mark.parametrize("accum,ckpt,crops", [(1, False, 0), (2, False, 0), (1, True, 0), (1, False, 3)])
+def test_engine_data_parallel_two_ranks_match_single_process(dx, tmp_path, accum, ckpt, crops):
     """Two ranks (gloo, both on this GPU -- RCCL needs one GPU per rank) run TrainEngine.step on their shard of a
     global batch; the result must equal the single-process step at the global batch: same loss, same
     updated weights, same centre.  Exercises broadcast, bucket hooks, centre all-reduce and the 1/world AdamW scale.
     accum = 2: gradient accumulation x data parallel (gradients are exchanged on the last micro-batch only).
-    ckpt: --grad-checkpoint under DP -- the buckets must still be launched DURING backward."""
+    ckpt: --grad-checkpoint under DP -- the buckets must still be launched DURING backward.
+    crops = 3: local crops on a model that is NOT scale-aware (cls / pos / registers then close the last bucket): pos_embed is reached
+    twice, directly by the global views and through the interpolated grid of the local ones; its slice of the arena may be exchanged
+    only when both gradients have landed (the ranks' position embeddings diverged silently)."""
     import os, socket, subprocess, sys
     from conftest import ROOT
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     worker = os.path.join(ROOT, "tests", "_dp_gpu_worker.py")
     outs = [str(tmp_path / f"r{r}.pt") for r in range(2)]
-    knobs = dict(DINOX_TEST_ACCUM=str(accum), DINOX_TEST_GRAD_CKPT="1" if ckpt else "")
+    knobs = dict(DINOX_TEST_ACCUM=str(accum), DINOX_TEST_GRAD_CKPT="1" if ckpt else "", DINOX_TEST_LOCAL_CROPS=str(crops),
+                 DINOX_TEST_SCALE_AWARE="0" if crops else "1")
     os.environ.update(knobs)
     env = dict(os.environ, DINOX_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2")
     procs = [subprocess.Popen([sys.executable, worker, outs[r]], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
@@ -1208,6 +1226,7 @@ def test_gemm_nt_areg_full_size_repeatable(dx, N, K, res, monkeypatch):
     parked fp32 words)."""
     ops, _ = dx
     monkeypatch.setenv("DINOX_NT_AREG_MAXK", str(1 << 30))
+    monkeypatch.setenv("DINOX_NT_PP", "0")          # (these shapes go to the ping-pong kernels by default since round 3: test_gemm_nt_pp_*)
     g = torch.Generator(device=DEV).manual_seed(0)
     M = 512 * 201
     A = (torch.randn(M, K, device=DEV, generator=g) * 0.5).bfloat16()
@@ -1230,11 +1249,12 @@ def test_gemm_nt_areg_full_size_repeatable(dx, N, K, res, monkeypatch):
 
 
 @pytest.mark.parametrize("K,N", [(1024, 1024), (1600, 384), (4096, 1024)])
-def test_gemm_nt_glds_repeatable(dx, K, N):
+def test_gemm_nt_glds_repeatable(dx, K, N, monkeypatch):
     """The LDS-DMA ring NT kernel at long K, 60 launches back to back, bit for bit.  K = 1024 and 4096 (ViT-L widths) end the K loop
     on ring slot 1, which is also where two waves park their accumulators: the last step's LDS reads must have returned before the
     barrier in front of the parking (csrc/gemm_bf16_glds.hip)."""
     ops, _ = dx
+    monkeypatch.setenv("DINOX_NT_PP", "0")
     g = torch.Generator(device=DEV).manual_seed(K + N)
     M = 128 * 400
     A = (torch.randn(M, K, device=DEV, generator=g) * 0.5).bfloat16()
@@ -1251,6 +1271,106 @@ def test_gemm_nt_glds_repeatable(dx, K, N):
     rows = torch.randint(0, M, (128,), device=DEV, generator=g)
     ref = A[rows].double() @ B.double().t() + res[rows].double()
     assert rel_l2(first[rows], ref) < 3e-3
+
+
+# ------------------------------------------------------------------------------------------ round 3: persistent ping-pong NT kernels
+PP_SHAPES = [(256, 256, 192), (512, 512, 384), (1000, 392, 384), (777, 1152, 384), (2048, 1536, 384), (1300, 384, 1536), (256 * 9 + 17, 1536, 192),
+             (3000, 1024, 1024), (515, 264, 4096), (5000, 384, 384), (300, 128, 448), (2049, 120, 192)]
+
+
+@pytest.mark.parametrize("mode", ["1", "2", "3"])
+@pytest.mark.parametrize("M,N,K", PP_SHAPES)
+def test_gemm_nt_pp(dx, M, N, K, mode, monkeypatch):
+    """The persistent ping-pong NT kernels (csrc/gemm_bf16_pp.hip: 256 x 256 tiles, csrc/gemm_bf16_pp128.hip: 256 x 128), forced onto
+    small and ragged shapes (DINOX_NT_PP = 1: tile width by shape, 2 / 3: every shape on the 128- / 256-wide form): every epilogue they
+    take -- plain, bias, GELU with and without its GELU' side tensor, x GELU', fp32 residual; bf16 and fp32 outputs -- against fp64 on
+    the same bf16 operands, with edge tiles in M and N (a wave whose rows / whose column strip lie entirely past the edge), tiles
+    of two to 64 K-tiles, a workgroup that owns several tiles (the request stream crosses tile boundaries) and fewer tiles than CUs."""
+    ops, _ = dx
+    monkeypatch.setenv("DINOX_NT_PP", mode)
+    if mode == "2" and K < 192:
+        pytest.skip("the 128-wide kernel needs three K-tiles")
+    g = torch.Generator().manual_seed(M + N + K)
+    A, B = (torch.randn(M, K, generator=g) * 0.5).bfloat16(), (torch.randn(N, K, generator=g) * (6.0 / math.sqrt(K))).bfloat16()
+    bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    Ad, Bd = A.to(DEV), B.to(DEV)
+    ref = A.double() @ B.double().t()
+    ops.TRACE_KERNELS = []
+    try:
+        c = ops.gemm(Ad, Bd, out_dtype=torch.float32)
+        cb = ops.gemm(Ad, Bd, bias=bias.to(DEV))
+        aux = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        act = ops.gemm(Ad, Bd, bias=bias.to(DEV), gelu=True, aux=aux, auxgrad=True)
+        act_t = ops.gemm(Ad, Bd, bias=bias.to(DEV), gelu=True)
+        y = ops.gemm(Ad, Bd, bias=bias.to(DEV), residual=res.to(DEV), out_dtype=torch.float32)
+        yb = ops.gemm(Ad, Bd, residual=res.to(DEV))
+        d = ops.gemm(Ad, Bd, dgelu=True, aux=aux, auxgrad=True)
+        auxf = torch.randn(M, N, generator=g).to(DEV)
+        d3 = ops.gemm(Ad, Bd, dgelu=True, aux=auxf, auxgrad=True, out_dtype=torch.float32)
+        names = set(ops.TRACE_KERNELS)
+        assert len(ops.TRACE_KERNELS) == 8 and names <= {"gemm_bf16_nt_pp", "gemm_bf16_nt_pp128"}, ops.TRACE_KERNELS
+        if mode != "1":
+            assert names == {"gemm_bf16_nt_pp128" if mode == "2" else "gemm_bf16_nt_pp"}
+    finally:
+        ops.TRACE_KERNELS = None
+    erf = lambda t: torch.erf(t / math.sqrt(2))
+    gelu_grad = lambda t: 0.5 * (1 + erf(t)) + t * torch.exp(-0.5 * t * t) / math.sqrt(2 * math.pi)
+    close(c, ref, 1e-5, 1e-4, "plain fp32 out")
+    assert rel_l2(cb.float(), ref + bias.double()) < 3e-3
+    pre = ref + bias.double()
+    assert rel_l2(act.float(), 0.5 * pre * (1 + erf(pre))) < 3e-3 and rel_l2(aux.float(), gelu_grad(pre)) < 3e-3
+    assert rel_l2(act_t.float(), 0.5 * pre * (1 + erf(pre))) < 3e-3
+    close(y, pre + res.double(), 1e-5, 1e-4, "bias + residual, fp32 out")
+    assert rel_l2(yb.float(), ref + res.double()) < 3e-3
+    assert rel_l2(d.float(), ref * aux.float().double().cpu()) < 3e-3
+    close(d3, ref * auxf.double().cpu(), 1e-5, 1e-4, "x GELU' from an fp32 side tensor, fp32 out")
+    # and the kernels they replace give the same numbers up to the summation order of the K loop
+    monkeypatch.setenv("DINOX_NT_PP", "0")
+    close(ops.gemm(Ad, Bd, bias=bias.to(DEV), residual=res.to(DEV), out_dtype=torch.float32), y, 2e-6, 2e-5, "pp vs the 128 x 128 kernels")
+
+
+@pytest.mark.parametrize("case", ["qkv", "fc2", "dact", "dx"])
+def test_gemm_nt_pp_full_size_repeatable(dx, case, monkeypatch):
+    """BASELINE size (M = 512 views x 201 tokens) through the ping-pong kernels as the DEFAULT policy dispatches them (qkv and the GELU'
+    product on 256 x 256 tiles, fc2 with its fp32 residual and the K = 1152 dX product on 256 x 128 tiles), 60 launches back to back:
+    no atomics, so every launch must reproduce the first bit for bit (a missed wait on a landed K-tile, a request overtaking a read
+    or a staging tile overwritten too early shows up as a sporadic difference), and sampled rows must match fp64."""
+    ops, _ = dx
+    monkeypatch.delenv("DINOX_NT_PP", raising=False)
+    g = torch.Generator(device=DEV).manual_seed(1)
+    M = 512 * 201
+    N, K = {"qkv": (1152, 384), "fc2": (384, 1536), "dact": (1536, 384), "dx": (384, 1152)}[case]
+    A = (torch.randn(M, K, device=DEV, generator=g) * 0.5).bfloat16()
+    B = (torch.randn(N, K, device=DEV, generator=g) * 0.5).bfloat16()
+    bias = torch.randn(N, device=DEV, generator=g)
+    r = torch.randn(M, N, device=DEV, generator=g) if case == "fc2" else None
+    aux = torch.randn(M, N, device=DEV, generator=g).bfloat16() if case == "dact" else None
+    if case == "qkv":
+        run = lambda: ops.gemm(A, B, bias=bias)
+    elif case == "fc2":
+        run = lambda: ops.gemm(A, B, bias=bias, residual=r, out_dtype=torch.float32)
+    elif case == "dact":
+        run = lambda: ops.gemm(A, B, dgelu=True, aux=aux, auxgrad=True)
+    else:
+        run = lambda: ops.gemm(A, B)
+    ops.TRACE_KERNELS = []
+    try:
+        first = run()
+        assert ops.TRACE_KERNELS == ["gemm_bf16_nt_pp" if case in ("qkv", "dact") else "gemm_bf16_nt_pp128"], ops.TRACE_KERNELS
+    finally:
+        ops.TRACE_KERNELS = None
+    for _ in range(60):
+        assert torch.equal(run(), first)
+    assert bool(torch.isfinite(first.float()).all())
+    rows = torch.cat([torch.randint(0, M, (256,), device=DEV, generator=g), torch.arange(M - 64, M, device=DEV), torch.arange(0, 64, device=DEV)])
+    ref = A[rows].double() @ B.double().t()
+    if case in ("qkv", "fc2"):
+        ref = ref + bias.double()
+    if case == "fc2":
+        ref = ref + r[rows].double()
+    if case == "dact":
+        ref = ref * aux[rows].double()
+    assert rel_l2(first[rows].float(), ref) < 3e-3
 
 
 # ------------------------------------------------------------------------------------------ round 2: cross-implementation checkpoints, cache staleness

@@ -50,7 +50,7 @@ for _p in (ROOT, os.path.join(ROOT, "dino-x_amd")):
 
 PEAK_BF16_DENSE_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16 MFMA
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E ~8 TB/s
-PMC_FILE = "r02_pmc_traffic.json"  # profiles/: per-kernel HBM bytes from the rocprofv3 --pmc passes of this same command
+PMC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json")  # profiles/: per-kernel HBM bytes from the rocprofv3 --pmc passes of this same command, newest first
 
 
 def fwd_flops_per_image(img=224, patch=16, dim=384, depth=12, out_dim=8192, regs=4, gram=True):
@@ -239,8 +239,9 @@ def timed(wl, steps, warmup, barrier, note=None, timer=None):
 
 
 def secondary(dev, note) -> dict:
-    """Short (3 warm-up + 2 x 8 timed steps, the better round) measurements of the other single-GPU BASELINE configs, so that the driver's record --
-    not a builder log -- holds them.  Each frees its memory before the next."""
+    """Short (3 warm-up + 2 x 8 timed steps) measurements of the other single-GPU BASELINE configs, so that the driver's record -- not a
+    builder log -- holds them.  `value` / `ms_per_step` are the MEAN of the two rounds (the protocol the headline and the baselines can be
+    compared with); the better round rides along as `best_ms_per_step`.  Each frees its memory before the next."""
     import gc
     import torch
     out = {}
@@ -264,11 +265,12 @@ def secondary(dev, note) -> dict:
         try:
             ops.dw_stream.enabled = was or bool(kw.pop("dw_stream", False))
             wl = Workload(dev, 0, **kw)
-            dt = min(timed(wl, 8, 3, sync), timed(wl, 8, 0, sync))     # two rounds of eight, the better one: a single stall (an allocation of a
-                                                                        # new size, a clock ramp) otherwise moves an 8-step figure by 30 %
+            rounds = [timed(wl, 8, 3, sync), timed(wl, 8, 0, sync)]    # two rounds of eight (a single stall -- an allocation of a new size, a
+            dt = sum(rounds) / 2                                        # clock ramp -- moves one 8-step figure by up to 30 %: both are reported)
             scal = wl.eng.scalars()
             sps = wl.B * 8 / dt
-            out[name] = {"workload": what, "value": round(sps, 1), "unit": "samples/s", "ms_per_step": round(1e3 * dt / 8, 3), "steps": 8, "warmup": 3,
+            out[name] = {"workload": what, "value": round(sps, 1), "unit": "samples/s", "ms_per_step": round(1e3 * dt / 8, 3),
+                         "best_ms_per_step": round(1e3 * min(rounds) / 8, 3), "protocol": "mean of 2 rounds x 8 steps after 3 warm-up steps", "steps": 16, "warmup": 3,
                          "views_per_s": round((2 + wl.L) * sps, 1), "step_tflops": round(sps * wl.gflop_per_sample() / 1e3, 1),
                          "step_frac_of_mfma_peak": round(sps * wl.gflop_per_sample() / 1e3 / PEAK_BF16_DENSE_TFLOPS, 4), "loss": round(scal["loss"], 4)}
             note(f"secondary {name}: {out[name]['value']} samples/s, {out[name]['ms_per_step']} ms/step")
@@ -330,6 +332,18 @@ def main() -> None:
     kernels = timer.summary() if timer else {}
     split = wl.step_split() if not (args.graph or args.no_step_split) else None     # (every rank: the step holds collectives)
     overlapped = getattr(wl.eng.bucketer, "fired_in_backward", None)
+    # what the collectives really ran on: the backend of the process group, the number of ranks an all-reduce of ones sees, and the
+    # slowest rank's exposed communication (the `comm_exposed` phase of step_ms_split: what did not fit under backward)
+    dist_info = None
+    if world > 1:
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        exposed = torch.tensor([split["comm_exposed"] if split else -1.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(exposed, op=dist.ReduceOp.MAX)
+        bk = wl.eng.bucketer
+        dist_info = {"dist_backend": dist.get_backend(), "rccl_ranks_seen": int(ones.item()), "comm_exposed_ms_max_over_ranks": round(float(exposed), 3),
+                     "grad_bucket_bytes": [4 * (b_.hi - b_.lo) for b_ in bk.buckets], "grad_bytes_per_step": 4 * int(wl.eng.flat_g.numel()),
+                     "centre_allreduce_bytes": 4 * wl.out_dim}
 
     if rank == 0:
         samples_s = world * B * args.steps / dt
@@ -359,21 +373,26 @@ def main() -> None:
                         all_gemm_kernels={k: {"launches": v["launches"], "ms": round(v["ms"], 3),
                                               "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
                                               "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)} for k, v in kernels.items()})
-        if roof.get("kernel") == "gemm_bf16_nt_areg":
-            roof["family_note"] = ("since round 2 the 24 proj launches per step (the family's shortest and most bandwidth-efficient: 396 MB in 90 us) run in "
-                                   "gemm_bf16_rowln with the LayerNorm behind them; 77 launches are left here (qkv, fc1, GELU' product, dX of proj), so the "
-                                   "family average moved from 131 us / 0.387 to ~144 us / ~0.355 with every shape's time unchanged (DESIGN.md section 4)")
         # HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE and, in a
-        # separate run, WRITE_SIZE of this same command; FETCH doubled per the gfx950 correction) -- bench.py cannot
-        # run the profiler on itself, so the figure is read from profiles/ and is null when that file is absent.
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
-            fam = "dinox::" + roof.get("kernel", "")
-            if fam in pmc and args.model == "vit-small" and B == 256 and not L and not args.no_scale_aware:
-                roof["traffic"] = pmc[fam]["hbm_bytes_per_launch"]
-                roof["traffic_note"] = f"measured avg HBM bytes/launch (PMC, profiles/{PMC_FILE}) beside hbm.algorithmic_bytes_per_launch"
-        except (OSError, ValueError, KeyError):
-            pass
+        # separate run, WRITE_SIZE of this same command; FETCH doubled per the gfx950 correction) -- bench.py cannot run the
+        # profiler on itself, so the figure is read from profiles/.  It is reported only while the kernel sources are the ones the
+        # profile was taken on (its "_source_fingerprint" stamp, dinox.hostinfo.source_fingerprint): a stale profile gives null.
+        if args.model == "vit-small" and B == 256 and not L and not args.no_scale_aware:
+            from dinox.hostinfo import source_fingerprint
+            fp_now = source_fingerprint()
+            for pmc_file in PMC_FILES:
+                try:
+                    pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
+                except (OSError, ValueError):
+                    continue
+                fam = "dinox::" + roof.get("kernel", "")
+                if pmc.get("_source_fingerprint") != fp_now:
+                    roof["traffic_note"] = (f"profiles/{pmc_file} was taken on other kernel sources (stamp {pmc.get('_source_fingerprint')}, now {fp_now}): "
+                                            "traffic withheld until tools/refresh_profiles.sh is re-run")
+                elif fam in pmc:
+                    roof["traffic"] = pmc[fam]["hbm_bytes_per_launch"]
+                    roof["traffic_note"] = f"measured avg HBM bytes/launch (PMC, profiles/{pmc_file}, same kernel sources) beside hbm.algorithmic_bytes_per_launch"
+                break
         roof["step"] = {"gflop_per_sample": round(gf_sample, 2), "achieved": round(step_tflops, 2),
                         "frac": round(step_tflops / PEAK_BF16_DENSE_TFLOPS, 4)}
         views = "2 views/sample" if not L else f"2 global + {L} local {args.local_size}px views/sample"
@@ -396,6 +415,8 @@ def main() -> None:
         }
         if world > 1 and overlapped is not None:
             line["config"]["grad_buckets_launched_during_backward"] = f"{overlapped}/{len(wl.eng.bucketer.buckets)}"
+        if dist_info is not None:
+            line["config"].update(dist_info)
         default_cfg = args.model == "vit-small" and B == 256 and not L and not args.no_scale_aware and not args.fp32
         if world == 1 and not args.no_secondary and default_cfg:
             wl = None

@@ -50,7 +50,11 @@ def init_process_group(backend: Optional[str] = None) -> Tuple[int, int, int]:
             backend = os.environ.get("DINOX_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if torch.cuda.is_available():
             torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        # A rank that dies mid-step must take the job down, not leave its peers waiting in finish(): every collective carries this
+        # time-out (DINOX_DIST_TIMEOUT_S, default 30 min = torch's; the tests use a few seconds), after which the waiting ranks raise.
+        import datetime
+        timeout = datetime.timedelta(seconds=float(os.environ.get("DINOX_DIST_TIMEOUT_S") or 1800))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout)
     return rank, world, local
 
 
@@ -148,8 +152,12 @@ class GradBucketer:
         for b in self.buckets:
             if b.work is None:
                 b.work = dist.all_reduce(self.flat[b.lo:b.hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        for b in self.buckets:
-            b.work.wait()
+        for i, b in enumerate(self.buckets):
+            try:
+                b.work.wait()
+            except RuntimeError as e:          # a peer went away (or the time-out of init_process_group ran out): fail loudly, on every surviving rank
+                raise RuntimeError(f"gradient exchange failed in bucket {i} of {len(self.buckets)} (elements {b.lo}..{b.hi}): a peer rank is gone or "
+                                   f"stalled -- {e}") from e
             b.work = None
 
     def remove(self) -> None:

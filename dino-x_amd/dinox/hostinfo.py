@@ -22,3 +22,23 @@ def usable_cpus() -> int:
         except (OSError, ValueError):
             pass
     return max(1, n)
+
+
+def source_fingerprint() -> str:
+    """16 hex digits over the kernel sources (csrc/*.hip, *.h, the C-ABI header) this library is built from.  The GPU box's snapshot
+    carries no .git, so profiles/*.json are stamped with this instead of a commit hash: bench.py reports a profile's PMC figures only
+    while the kernels are the ones the profile was taken on."""
+    import glob
+    import hashlib
+    here = os.path.dirname(os.path.abspath(__file__))
+    csrc = os.path.join(os.path.dirname(here), "csrc")
+    files = sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")))
+    files.append(os.path.join(os.path.dirname(os.path.dirname(here)), "include", "dinox.h"))
+    hsh = hashlib.sha256()
+    for f in files:
+        try:
+            with open(f, "rb") as fh:
+                hsh.update(os.path.basename(f).encode() + b"\0" + fh.read())
+        except OSError:
+            pass
+    return hsh.hexdigest()[:16]

@@ -1343,6 +1343,11 @@ class PosInterpFn(torch.autograd.Function):
         out[0, :1].copy_(pf[0, :1])
         gemm(W, pf[0, 1:], transB=True, out=out[0, 1:])
         ctx.W = W
+        # A second path into pos_embed: it is counted like the direct one (TokensFn) and its gradient goes the same way -- into the
+        # gradient arena, announced to the bucketer once per use.  (Round 2 returned dpos to autograd here: under data parallelism with
+        # local crops the arena slice was then all-reduced when the GLOBAL pass had landed, before AccumulateGrad added this part.)
+        ctx.pos = pos if isinstance(pos, torch.nn.Parameter) else None
+        grad_sink.use(ctx.pos)
         return out
 
     @staticmethod
@@ -1352,7 +1357,7 @@ class PosInterpFn(torch.autograd.Function):
         dpos = torch.empty((1, 1 + W.shape[1], g.shape[2]), dtype=torch.float32, device=g.device)
         dpos[0, :1].copy_(g[0, :1])
         gemm(W, g[0, 1:], transA=True, transB=True, out=dpos[0, 1:])
-        return dpos, None
+        return small_grad(ctx.pos, dpos), None
 
 
 def interp_pos(pos: Tensor, g_out: int) -> Tensor:

@@ -94,13 +94,14 @@ typedef struct dinox_gemm_args {
   float* colsum;                       /* optional, transA = 1 only: colsum[m] = sum_k A(m,k) (overwritten; added to
                                         * under ACCUM, like C) -- the bias
                                         * gradient sum_rows(dY) rides along the dW = dY^T X product that already streams dY */
-  void* ws;                            /* optional workspace of dinox_gemm_ws_bytes() bytes, ZERO when first handed over (the library
-                                        * leaves it zero).  With it a split-K product (the dW = dY^T X products, K = every token of
-                                        * the batch) meets in a fixed-order two-stage reduction -- partial tiles by plain stores, the
-                                        * last workgroup of a tile sums them in split order -- instead of fp32 atomics: results are
-                                        * bit-reproducible from run to run, and 33 MB of memory-side atomics per launch (1.3 TB/s on
-                                        * this part) become plain stores (6 TB/s).  NULL: atomics as before.  One launch at a time
-                                        * per workspace (stream-ordered reuse is fine). */
+  void* ws;                            /* optional workspace of dinox_gemm_ws_bytes() bytes; its contents need not be initialised.  With it a
+                                        * split-K product (the dW = dY^T X products, K = every token of the batch) runs as TWO launches on
+                                        * the caller's stream: the split kernel stores its partial tiles there by plain stores, a reduction
+                                        * kernel then sums them in split order into C -- no counters, no atomics: results are
+                                        * bit-reproducible from run to run, and 33 MB of memory-side atomics per launch (1.3 TB/s on this
+                                        * part) become plain stores (6 TB/s).  NULL: fp32 atomics into C (one launch, not reproducible).
+                                        * One product at a time per workspace; reuse in stream order is fine.  (NT products ignore it,
+                                        * except that tools/pp_stamps.py hands the ping-pong kernels a diagnostic stamp buffer here.) */
 } dinox_gemm_args;
 
 int dinox_gemm(const dinox_gemm_args* args, void* stream);

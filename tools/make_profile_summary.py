@@ -63,7 +63,7 @@ md += ["", f"Total kernel time {total_ns / 1e6:.1f} ms over {steps} steps = {tot
        f"(never combined with a trace domain); summary by `tools/pmc_summary.py` in `{tag}_pmc_traffic.json` (FETCH_SIZE doubled: gfx950 reports half the "
        "bytes of 16-B/lane streaming reads, MI355X_MICROARCH.md; sanity check: `ln_fwd_kernel` must read its 158 MB fp32 input once).", "",
        "| kernel family | launches | HBM read / launch | HBM write / launch |", "|---|---|---|---|"]
-for k, v in list(pmc.items())[:14]:
+for k, v in [kv for kv in pmc.items() if not kv[0].startswith("_")][:14]:
     md.append(f"| `{k}` | {v['launches']} | {v['fetch_bytes_per_launch_x2_corrected'] / 1e6:.1f} MB | {v['write_bytes_per_launch'] / 1e6:.1f} MB |")
 md.append("")
 sq = sorted(glob.glob(os.path.join(src, "pmc_sq/**/*_counter_collection.csv"), recursive=True), key=os.path.getmtime)
@@ -78,7 +78,7 @@ if os.path.exists(mfma_json):
            "SQ_VALU_MFMA_BUSY_CYCLES / (dispatch duration x 2.03 GHz x 1024 SIMDs); wave states are fractions of SQ_WAVE_CYCLES (parked = s_waitcnt / "
            "barrier, issue-stalled = an instruction is ready but cannot issue, issuing = an instruction issues).", "",
            "| kernel family | launches | MFMA utilisation | parked | issue-stalled | issuing |", "|---|---|---|---|---|---|"]
-    for k, v in list(mf.items())[:8]:
+    for k, v in [kv for kv in mf.items() if not kv[0].startswith("_")][:8]:
         md.append(f"| `{k}` | {v['launches']} | {100 * v['mfma_util']:.1f} % | {v['wave_wait_any']:.2f} | {v['wave_wait_inst']:.2f} | {v['wave_active_inst']:.2f} |")
     md.append("")
 open(os.path.join(prof, f"{tag}_bench_bs256_summary.md"), "w").write("\n".join(md))

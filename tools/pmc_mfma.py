@@ -8,6 +8,16 @@ their ratios say where resident waves spend their time (parked on s_waitcnt/barr
 usage: pmc_mfma.py <counter_collection.csv> <out.json>"""
 import collections, csv, json, sys
 
+
+def _fingerprint():
+    import importlib.util, os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dino-x_amd", "dinox", "hostinfo.py")
+    spec = importlib.util.spec_from_file_location("_dinox_hostinfo", path)      # (plain Python: no GPU, no library load)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.source_fingerprint()
+
+
 SIMDS = 1024
 CLOCK_GHZ = 2.03
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
@@ -31,6 +41,7 @@ for fam, c in sorted(agg.items(), key=lambda kv: -kv[1].get("_ns", 0)):
                 "mfma_util": round(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (act * SIMDS), 4),
                 "wave_wait_any": round(c.get("SQ_WAIT_ANY", 0.0) / wc, 3), "wave_wait_inst": round(c.get("SQ_WAIT_INST_ANY", 0.0) / wc, 3),
                 "wave_active_inst": round(c.get("SQ_ACTIVE_INST_ANY", 0.0) / wc, 3)}
+out["_source_fingerprint"] = _fingerprint()      # the kernel sources these figures belong to (bench.py checks it)
 json.dump(out, open(sys.argv[2], "w"), indent=1)
-for k, v in list(out.items())[:12]:
+for k, v in [kv for kv in out.items() if not kv[0].startswith("_")][:12]:
     print(f"{k:36s} launches {v['launches']:5d}  MFMA util {100 * v['mfma_util']:5.1f} %   waves: parked {v['wave_wait_any']:.2f}  issue-stalled {v['wave_wait_inst']:.2f}  issuing {v['wave_active_inst']:.2f}")

@@ -9,6 +9,15 @@ import json
 import sys
 
 
+def _fingerprint():
+    import importlib.util, os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dino-x_amd", "dinox", "hostinfo.py")
+    spec = importlib.util.spec_from_file_location("_dinox_hostinfo", path)      # (plain Python: no GPU, no library load)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.source_fingerprint()
+
+
 def load(path):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
@@ -26,6 +35,7 @@ for fam in sorted(fe, key=lambda k: -sum(fe[k])):
     w = 1024.0 * sum(wr.get(fam, [0.0])) / max(1, len(wr.get(fam, [0.0])))
     out[fam] = {"launches": n, "fetch_bytes_per_launch_x2_corrected": round(f), "write_bytes_per_launch": round(w),
                 "hbm_bytes_per_launch": round(f + w)}
+out["_source_fingerprint"] = _fingerprint()      # the kernel sources these figures belong to (bench.py checks it)
 json.dump(out, open(sys.argv[3], "w"), indent=1)
-for k, v in list(out.items())[:12]:
+for k, v in [kv for kv in out.items() if not kv[0].startswith("_")][:12]:
     print(f"{k:40s} launches {v['launches']:5d}  fetch {v['fetch_bytes_per_launch_x2_corrected'] / 1e6:9.1f} MB  write {v['write_bytes_per_launch'] / 1e6:9.1f} MB")

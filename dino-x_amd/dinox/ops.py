@@ -536,50 +536,72 @@ def _use_f32_products(qkv: Tensor, N: int, d: int) -> bool:
 
 
 def _bf16_attention_needs_products(qkv: Tensor, N: int, d: int, fwd: bool) -> bool:
-    """bf16 mode, a shape outside the MFMA attention kernels (head size 64; <= 288 tokens forward, <= 544 backward), big enough to matter."""
+    """bf16 mode, a head size the MFMA attention kernels do not take (not a multiple of 8, or above 128), big enough to matter.  Since round 3
+    every other shape runs on the device kernels: head size 64 up to 288 / 544 tokens on the whole-strip kernels (csrc/attention_bf16.hip),
+    longer sequences and head sizes up to 128 -- ViT-g: 88 -- on the tiled ones (csrc/attention_flash.hip)."""
     if qkv.dtype != torch.bfloat16 or _ATTN_F32_REF or N < 32 or qkv.shape[0] * N < 4096:
         return False
-    return d != 64 or N > (288 if fwd else 544)
+    return d % 8 != 0 or d > 128
+
+
+_PRODUCTS_BUDGET = 256 << 20      # bytes of fp32 scores per buffer of the product form (S, and dP in the backward)
+
+
+def _product_chunks(B: int, N: int):
+    """Batch ranges of the fp32 product form such that a [b, N, N] fp32 score buffer stays within _PRODUCTS_BUDGET (at bs 256
+    and 785 tokens the un-chunked buffers were 1.26 GB each)."""
+    per = max(1, _PRODUCTS_BUDGET // (4 * N * N))
+    return [(b0, min(B, b0 + per)) for b0 in range(0, B, per)]
 
 
 def _attention_fwd_f32_products(qkv: Tensor, heads: int, o: Tensor, lse: Tensor) -> None:
     """softmax(Q K^T / sqrt(d)) V per head as S = scale Q K^T (NT), softmax rows, O = P V -- operands addressed inside the packed qkv
-    [B, N, 3, heads, d] and o [B, N, heads, d] by leading dimensions and batch strides."""
+    [B, N, 3, heads, d] and o [B, N, heads, d] by leading dimensions and batch strides; the batch is walked in chunks that keep the
+    score buffer within _PRODUCTS_BUDGET."""
     B, N, C3 = qkv.shape
     Cc = C3 // 3
     d = Cc // heads
     scale = 1.0 / math.sqrt(d)
-    S = torch.empty((B, N, N), dtype=torch.float32, device=qkv.device)
-    q0, o0, E = qkv.data_ptr(), o.data_ptr(), 4
-    for h in range(heads):
-        qh, kh, vh = q0 + E * h * d, q0 + E * (Cc + h * d), q0 + E * (2 * Cc + h * d)
-        _gemm_f32_raw(qh, kh, _p(S), N, N, d, C3, C3, N, B, N * C3, N * C3, N * N, False, False, scale)          # S[b] = scale Q K^T
-        check(lib.dinox_softmax_rows(_p(S), lse.data_ptr() + E * h * N, B * N, N, N, heads * N, _stream()), "dinox_softmax_rows")
-        _gemm_f32_raw(_p(S), vh, o0 + E * h * d, N, d, N, N, C3, Cc, B, N * N, N * C3, N * Cc, False, True)      # O[b] = P V
+    chunks = _product_chunks(B, N)
+    S = torch.empty((chunks[0][1] - chunks[0][0], N, N), dtype=torch.float32, device=qkv.device)
+    E = 4
+    for b0, b1 in chunks:
+        nb = b1 - b0
+        q0, o0 = qkv.data_ptr() + E * b0 * N * C3, o.data_ptr() + E * b0 * N * Cc
+        for h in range(heads):
+            qh, kh, vh = q0 + E * h * d, q0 + E * (Cc + h * d), q0 + E * (2 * Cc + h * d)
+            _gemm_f32_raw(qh, kh, _p(S), N, N, d, C3, C3, N, nb, N * C3, N * C3, N * N, False, False, scale)          # S[b] = scale Q K^T
+            check(lib.dinox_softmax_rows(_p(S), lse.data_ptr() + E * (b0 * heads + h) * N, nb * N, N, N, heads * N, _stream()), "dinox_softmax_rows")
+            _gemm_f32_raw(_p(S), vh, o0 + E * h * d, N, d, N, N, C3, Cc, nb, N * N, N * C3, N * Cc, False, True)      # O[b] = P V
 
 
 def _attention_bwd_f32_products(do: Tensor, qkv: Tensor, o: Tensor, lse: Tensor, heads: int, dqkv: Tensor) -> None:
     """Backward of the same: P = exp(S - lse) recomputed per head, dP = dO V^T, dS = P o (dP - rowsum(P o dP)) * scale, then
-    dV = P^T dO, dQ = dS K, dK = dS^T Q written straight into the packed dqkv."""
+    dV = P^T dO, dQ = dS K, dK = dS^T Q written straight into the packed dqkv (batch chunks as in the forward)."""
     B, N, C3 = qkv.shape
     Cc = C3 // 3
     d = Cc // heads
     scale = 1.0 / math.sqrt(d)
     dev = qkv.device
-    S = torch.empty((B, N, N), dtype=torch.float32, device=dev)
-    dP = torch.empty((B, N, N), dtype=torch.float32, device=dev)
-    q0, g0, do0, E = qkv.data_ptr(), dqkv.data_ptr(), do.data_ptr(), 4
-    for h in range(heads):
-        qh, kh, vh = q0 + E * h * d, q0 + E * (Cc + h * d), q0 + E * (2 * Cc + h * d)
-        dqh, dkh, dvh = g0 + E * h * d, g0 + E * (Cc + h * d), g0 + E * (2 * Cc + h * d)
-        doh = do0 + E * h * d
-        _gemm_f32_raw(qh, kh, _p(S), N, N, d, C3, C3, N, B, N * C3, N * C3, N * N, False, False, scale)          # S = scale Q K^T
-        _gemm_f32_raw(doh, vh, _p(dP), N, N, d, Cc, C3, N, B, N * Cc, N * C3, N * N, False, False)               # dP = dO V^T
-        check(lib.dinox_softmax_bwd_rows(_p(S), _p(dP), lse.data_ptr() + E * h * N, scale, B * N, N, N, heads * N, _stream()),
-              "dinox_softmax_bwd_rows")                                                                              # S <- P, dP <- dS
-        _gemm_f32_raw(_p(S), doh, dvh, N, d, N, N, Cc, C3, B, N * N, N * Cc, N * C3, True, True)                  # dV = P^T dO
-        _gemm_f32_raw(_p(dP), kh, dqh, N, d, N, N, C3, C3, B, N * N, N * C3, N * C3, False, True)                 # dQ = dS K
-        _gemm_f32_raw(_p(dP), qh, dkh, N, d, N, N, C3, C3, B, N * N, N * C3, N * C3, True, True)                  # dK = dS^T Q
+    chunks = _product_chunks(B, N)
+    nb0 = chunks[0][1] - chunks[0][0]
+    S = torch.empty((nb0, N, N), dtype=torch.float32, device=dev)
+    dP = torch.empty((nb0, N, N), dtype=torch.float32, device=dev)
+    E = 4
+    for b0, b1 in chunks:
+        nb = b1 - b0
+        q0, g0, do0 = qkv.data_ptr() + E * b0 * N * C3, dqkv.data_ptr() + E * b0 * N * C3, do.data_ptr() + E * b0 * N * Cc
+        for h in range(heads):
+            qh, kh, vh = q0 + E * h * d, q0 + E * (Cc + h * d), q0 + E * (2 * Cc + h * d)
+            dqh, dkh, dvh = g0 + E * h * d, g0 + E * (Cc + h * d), g0 + E * (2 * Cc + h * d)
+            doh = do0 + E * h * d
+            _gemm_f32_raw(qh, kh, _p(S), N, N, d, C3, C3, N, nb, N * C3, N * C3, N * N, False, False, scale)          # S = scale Q K^T
+            _gemm_f32_raw(doh, vh, _p(dP), N, N, d, Cc, C3, N, nb, N * Cc, N * C3, N * N, False, False)               # dP = dO V^T
+            check(lib.dinox_softmax_bwd_rows(_p(S), _p(dP), lse.data_ptr() + E * (b0 * heads + h) * N, scale, nb * N, N, N, heads * N, _stream()),
+                  "dinox_softmax_bwd_rows")                                                                              # S <- P, dP <- dS
+            _gemm_f32_raw(_p(S), doh, dvh, N, d, N, N, Cc, C3, nb, N * N, N * Cc, N * C3, True, True)                  # dV = P^T dO
+            _gemm_f32_raw(_p(dP), kh, dqh, N, d, N, N, C3, C3, nb, N * N, N * C3, N * C3, False, True)                 # dQ = dS K
+            _gemm_f32_raw(_p(dP), qh, dkh, N, d, N, N, C3, C3, nb, N * N, N * C3, N * C3, True, True)                  # dK = dS^T Q
 
 
 def attention_fwd(qkv: Tensor, heads: int):

@@ -228,9 +228,15 @@ def test_attention_module_golden(dx, mode):
             assert rel_l2(dict(m.named_parameters())[k].grad, v) < 2.5e-2, k
 
 
-@pytest.mark.parametrize("B,N,h,d", [(2, 201, 6, 64), (1, 19, 2, 32), (3, 64, 1, 64), (1, 261, 2, 64), (2, 7, 2, 16), (40, 250, 6, 64), (50, 37, 6, 64), (3, 530, 2, 64), (60, 201, 6, 64)])
+@pytest.mark.parametrize("B,N,h,d", [(2, 201, 6, 64), (1, 19, 2, 32), (3, 64, 1, 64), (1, 261, 2, 64), (2, 7, 2, 16), (40, 250, 6, 64), (50, 37, 6, 64), (3, 530, 2, 64), (60, 201, 6, 64),
+                                     # round 3, the tiled kernels (csrc/attention_flash.hip): 448 / 512 px inputs, the vit-giant head size, 128, ragged tails
+                                     (8, 789, 6, 64), (4, 1029, 6, 64), (8, 261, 16, 88), (2, 300, 2, 32), (3, 333, 3, 128), (17, 290, 2, 40), (2, 1342, 2, 88)])
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 def test_attention_core_vs_np(dx, B, N, h, d, mode):
+    """softmax(Q K^T / sqrt(d)) V and its backward on the packed qkv tensor against the float64 NumPy statement (oracle/kernels_np.py):
+    the whole-strip MFMA kernels (d = 64, up to 288 / 544 tokens), the tiled MFMA kernels (any length, d <= 128: (8, 789, 6, 64),
+    (4, 1029, 6, 64) and (8, 261, 16, 88) are the shapes --img-size 448 / 512 and the vit-giant preset reach), the per-lane reference
+    kernels (small / fp32) and the fp32 product form (full-size fp32)."""
     ops, _ = dx
     from oracle import kernels_np as K
     rng = np.random.default_rng(N * 7 + d)
@@ -1737,35 +1743,47 @@ def test_fp32_mode_fast_paths_equal_the_reference_kernels(dx):
     close(o1, o0, 1e-5, 1e-6, "fp32 attention o")
     close(l1, l0, 1e-6, 1e-6, "fp32 attention lse")
     close(d1, d0, 2e-5, 1e-6, "fp32 attention dqkv")
-    # (a') bf16 mode, a head size the MFMA attention kernels do not take (ViT-g: 88): the product form on a float copy
-    Bg, Ng, Hg, dg = 48, 100, 4, 88
+    # (a') bf16 mode, shapes outside the whole-strip MFMA kernels: since round 3 the tiled MFMA kernels (csrc/attention_flash.hip) take
+    # every head size that is a multiple of 8 up to 128 and any length; they must agree with the per-lane reference kernels
+    # (DINOX_ATTN_NO_FLASH=1 at the C ABI) to bf16 round-off -- ViT-g's head size 88, and head size 64 at 600 tokens
+    import os
+    for (Bg, Ng, Hg, dg) in ((48, 100, 4, 88), (8, 600, 2, 64)):
+        qb = (torch.randn(Bg, Ng, 3 * Hg * dg, device="cuda", generator=g) * 0.5).bfloat16()
+        dob = (torch.randn(Bg, Ng, Hg * dg, device="cuda", generator=g) * 0.1).bfloat16()
+        assert not ops._bf16_attention_needs_products(qb, Ng, dg, fwd=True) and not ops._bf16_attention_needs_products(qb, Ng, dg, fwd=False)
+        ob, lb = ops.attention_fwd(qb, Hg)
+        db_ = ops.attention_bwd(dob, qb, ob, lb, Hg)
+        os.environ["DINOX_ATTN_NO_FLASH"] = "1"
+        try:
+            orf, lrf = ops.attention_fwd(qb, Hg)
+            drf = ops.attention_bwd(dob, qb, orf, lrf, Hg)
+        finally:
+            del os.environ["DINOX_ATTN_NO_FLASH"]
+        assert ob.dtype == torch.bfloat16 and db_.dtype == torch.bfloat16
+        assert rel_l2(ob.float(), orf.float()) < 6e-3 and rel_l2(db_.float(), drf.float()) < 1e-2
+        close(lb, lrf, 1e-4, 1e-4, f"lse (head size {dg}, {Ng} tokens)")
+    # (a'') bf16 mode, a head size that is NOT a multiple of 8 (no preset has one): the exact-fp32 product form on a float copy, in batch
+    # chunks that keep the score buffer within ops._PRODUCTS_BUDGET (shrunk here so that the chunk loop really runs)
+    Bg, Ng, Hg, dg = 48, 100, 4, 84
     qb = (torch.randn(Bg, Ng, 3 * Hg * dg, device="cuda", generator=g) * 0.5).bfloat16()
     dob = (torch.randn(Bg, Ng, Hg * dg, device="cuda", generator=g) * 0.1).bfloat16()
     assert ops._bf16_attention_needs_products(qb, Ng, dg, fwd=True)
-    ob, lb = ops.attention_fwd(qb, Hg)
-    db_ = ops.attention_bwd(dob, qb, ob, lb, Hg)
+    budget = ops._PRODUCTS_BUDGET
+    ops._PRODUCTS_BUDGET = 10 * 4 * Ng * Ng                         # 10 images per chunk: 48 = 4 x 10 + 8
+    try:
+        assert len(ops._product_chunks(Bg, Ng)) == 5
+        ob, lb = ops.attention_fwd(qb, Hg)
+        db_ = ops.attention_bwd(dob, qb, ob, lb, Hg)
+    finally:
+        ops._PRODUCTS_BUDGET = budget
     ops._ATTN_F32_REF = True
     try:
         orf, lrf = ops.attention_fwd(qb, Hg)
         drf = ops.attention_bwd(dob, qb, orf, lrf, Hg)
     finally:
         ops._ATTN_F32_REF = False
-    assert ob.dtype == torch.bfloat16 and db_.dtype == torch.bfloat16
     assert rel_l2(ob.float(), orf.float()) < 6e-3 and rel_l2(db_.float(), drf.float()) < 1e-2
-    close(lb, lrf, 1e-4, 1e-4, "lse (head size 88)")
-    # (a'') bf16 mode, head size 64 but 600 tokens (> 288 forward, > 544 backward: outside the MFMA kernels)
-    ql = (torch.randn(8, 600, 3 * 2 * 64, device="cuda", generator=g) * 0.5).bfloat16()
-    dol = (torch.randn(8, 600, 2 * 64, device="cuda", generator=g) * 0.1).bfloat16()
-    assert ops._bf16_attention_needs_products(ql, 600, 64, fwd=True) and ops._bf16_attention_needs_products(ql, 600, 64, fwd=False)
-    ol, ll = ops.attention_fwd(ql, 2)
-    dl = ops.attention_bwd(dol, ql, ol, ll, 2)
-    ops._ATTN_F32_REF = True
-    try:
-        orl, lrl = ops.attention_fwd(ql, 2)
-        drl = ops.attention_bwd(dol, ql, orl, lrl, 2)
-    finally:
-        ops._ATTN_F32_REF = False
-    assert rel_l2(ol.float(), orl.float()) < 6e-3 and rel_l2(dl.float(), drl.float()) < 1e-2
+    close(lb, lrf, 1e-4, 1e-4, "lse (head size 84, product form in chunks)")
     # (b) dW = dy^T x with K = 16384 tokens, accumulated into an existing gradient, with the bias gradient
     K, M, Nn = 16384, 384, 256
     dy, x = torch.randn(K, M, device="cuda", generator=g), torch.randn(K, Nn, device="cuda", generator=g)

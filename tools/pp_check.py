@@ -22,7 +22,7 @@ def rf(*s):
 
 
 def run(pp, fn):
-    os.environ["DINOX_NT_PP"] = os.environ.get("PP_MODE", "1") if pp else "0"
+    os.environ["DINOX_NT_PP"] = (os.environ.get("PP_MODE_V") or os.environ.get("PP_MODE", "1")) if pp else "0"
     ops.TRACE_KERNELS = []
     out = fn()
     names = ops.TRACE_KERNELS
@@ -140,6 +140,7 @@ def timing():
     times = {(n, v[0]): [] for n in names for v in variants}
     def setenv(v):
         os.environ["DINOX_PP_ORDER"] = v[2]
+        os.environ["PP_MODE_V"] = v[4] if len(v) > 4 else ""
         if v[3] is None:
             os.environ.pop("DINOX_PP_STAGGER", None)
         else:
@@ -154,7 +155,7 @@ def timing():
         for n in names:
             for v in variants:
                 setenv(v)
-                os.environ["DINOX_NT_PP"] = os.environ.get("PP_MODE", "1") if v[1] else "0"
+                os.environ["DINOX_NT_PP"] = (os.environ.get("PP_MODE_V") or os.environ.get("PP_MODE", "1")) if v[1] else "0"
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 cases[n][0]()

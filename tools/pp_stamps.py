@@ -8,7 +8,7 @@ import torch
 from dinox import ops
 from dinox._lib import lib, GemmArgs, check, BF16, F32, EPI_BIAS, EPI_GELU, EPI_DGELU, EPI_AUXGRAD, EPI_RESIDUAL
 
-os.environ["DINOX_NT_PP"] = "1"
+os.environ["DINOX_NT_PP"] = os.environ.get("PP_MODE", "1")
 os.environ.setdefault("DINOX_PP_ORDER", "1")
 dev = "cuda"
 g = torch.Generator(device=dev).manual_seed(0)

@@ -1,4 +1,6 @@
 // gemm.hip -- dinox_gemm dispatcher + column sums.
+#include <cstring>
+
 #include "common.h"
 #include "gemm_common.h"
 
@@ -40,6 +42,37 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const void* __restrict__ x
 }  // namespace dinox
 
 using namespace dinox;
+
+// ---------------------------------------------------------------- per-launch timing (dinox_gemm_timer_*: diagnostic, bench.py's roofline)
+#include <map>
+#include <mutex>
+#include <string>
+#include <tuple>
+#include <vector>
+namespace {
+struct TimerRec {
+  int64_t launches = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+};
+typedef std::tuple<std::string, int64_t, int64_t, int64_t, int64_t, int, int, int, int, int> TimerKey;   // kernel M N K batch epi in out aux shared_b
+std::mutex g_timer_mu;
+bool g_timer_on = false;
+int g_timer_every = 16;
+uint64_t g_timer_n = 0;
+std::map<TimerKey, TimerRec> g_timer;
+std::vector<hipEvent_t> g_timer_pool;
+
+hipEvent_t timer_event() {
+  if (!g_timer_pool.empty()) {
+    hipEvent_t e = g_timer_pool.back();
+    g_timer_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+}  // namespace
 
 static void to_params(const dinox_gemm_args* a, GemmParams& p) {
   p.A = a->A; p.B = a->B; p.C = a->C;
@@ -89,16 +122,82 @@ extern "C" int dinox_gemm(const dinox_gemm_args* a, void* stream) {
   GemmParams p;
   to_params(a, p);
   hipStream_t st = as_stream(stream);
-  if (p.in_dtype == DINOX_BF16) {
-    const int rc = launch_gemm_bf16(p, st);          // the TN kernel produces colsum itself
-    if (rc != DINOX_EUNSUPPORTED) return rc;
+  // timing (dinox_gemm_timer_start .. stop): count every launch per (kernel, shape), bracket one in `every` with an event pair
+  hipEvent_t e1 = nullptr;
+  if (g_timer_on) {
+    std::lock_guard<std::mutex> lk(g_timer_mu);
+    if (g_timer_on) {
+      const char* v = gemm_bf16_variant(p);
+      TimerRec& r = g_timer[TimerKey(v ? v : "gemm_f32", p.M, p.N, p.K, p.batch, p.epilogue, p.in_dtype, p.out_dtype,
+                                     (p.aux && (p.epilogue & (DINOX_EPI_GELU | DINOX_EPI_DGELU))) ? 1 : 0, (p.batch > 1 && p.strideB == 0) ? 1 : 0)];
+      r.launches++;
+      ++g_timer_n;
+      if (g_timer_every <= 1 || (((g_timer_n * 2654435761ull) & 0xffffffffull) * (uint64_t)g_timer_every >> 32) == 0) {
+        hipEvent_t e0 = timer_event();
+        e1 = timer_event();
+        if (e0 && e1) {
+          (void)hipEventRecord(e0, st);
+          r.ev.emplace_back(e0, e1);
+        } else {
+          e1 = nullptr;
+        }
+      }
+    }
+  }
+  int rc = DINOX_EUNSUPPORTED;
+  if (p.in_dtype == DINOX_BF16) rc = launch_gemm_bf16(p, st);          // the TN kernel produces colsum itself
+  if (rc == DINOX_EUNSUPPORTED) {
     // shape/layout outside the MFMA-bf16 kernel's envelope: exact-fp32 MFMA on the bf16 values.
+    rc = 0;
+    if (p.colsum)                                    // A is stored [K][M]: its column sums are the wanted vector
+      rc = dinox_colsum(p.A, p.colsum, p.K, p.M, p.lda, p.in_dtype, (p.epilogue & DINOX_EPI_ACCUM) ? 1 : 0, stream);
+    if (!rc) rc = launch_gemm_f32(p, st);
   }
-  if (p.colsum) {                                    // A is stored [K][M]: its column sums are the wanted vector
-    const int rc = dinox_colsum(p.A, p.colsum, p.K, p.M, p.lda, p.in_dtype, (p.epilogue & DINOX_EPI_ACCUM) ? 1 : 0, stream);
-    if (rc) return rc;
+  if (e1) (void)hipEventRecord(e1, st);
+  return rc;
+}
+
+extern "C" int dinox_gemm_timer_start(int every) {
+  std::lock_guard<std::mutex> lk(g_timer_mu);
+  for (auto& kv : g_timer)
+    for (auto& pr : kv.second.ev) {
+      g_timer_pool.push_back(pr.first);
+      g_timer_pool.push_back(pr.second);
+    }
+  g_timer.clear();
+  g_timer_every = every < 1 ? 1 : every;
+  g_timer_n = 0;
+  g_timer_on = true;
+  return 0;
+}
+
+extern "C" int64_t dinox_gemm_timer_stop(char* buf, int64_t buflen) {
+  std::lock_guard<std::mutex> lk(g_timer_mu);
+  g_timer_on = false;
+  std::string out;
+  char line[512];
+  for (auto& kv : g_timer) {
+    double ms = 0.0;
+    int64_t timed = 0;
+    for (auto& pr : kv.second.ev) {
+      float t = 0.f;
+      if (hipEventSynchronize(pr.second) == hipSuccess && hipEventElapsedTime(&t, pr.first, pr.second) == hipSuccess) {
+        ms += t;
+        ++timed;
+      }
+      g_timer_pool.push_back(pr.first);
+      g_timer_pool.push_back(pr.second);
+    }
+    const TimerKey& k = kv.first;
+    snprintf(line, sizeof line, "%s %lld %lld %lld %lld %d %d %d %d %d %lld %lld %.6f\n", std::get<0>(k).c_str(), (long long)std::get<1>(k),
+             (long long)std::get<2>(k), (long long)std::get<3>(k), (long long)std::get<4>(k), std::get<5>(k), std::get<6>(k), std::get<7>(k),
+             std::get<8>(k), std::get<9>(k), (long long)kv.second.launches, (long long)timed, ms);
+    out += line;
   }
-  return launch_gemm_f32(p, st);
+  g_timer.clear();
+  if (!buf || (int64_t)out.size() + 1 > buflen) return -1;
+  memcpy(buf, out.c_str(), out.size() + 1);
+  return (int64_t)out.size();
 }
 
 extern "C" int dinox_colsum(const void* x, float* out, int64_t M, int64_t N, int64_t ldx, int dtype, int accumulate,

@@ -35,6 +35,33 @@ class GemmArgs(C.Structure):
     ]
 
 
+class BlockFwdArgs(C.Structure):
+    """struct dinox_block_fwd_args (include/dinox.h)."""
+    _fields_ = [
+        ("V", i64), ("N", i64), ("D", i32), ("H", i32), ("heads", i32), ("train", i32), ("fuse_proj_ln", i32), ("fuse_fc2_ln", i32), ("eps", f32),
+        ("x0", vp), ("xn1_in", vp), ("mean1_in", vp), ("rstd1_in", vp), ("xn1", vp), ("mean1", vp), ("rstd1", vp),
+        ("qkv", vp), ("o", vp), ("lse", vp), ("x1", vp), ("xn2", vp), ("mean2", vp), ("rstd2", vp), ("act", vp), ("pre", vp), ("x2", vp),
+        ("next_g", vp), ("next_b", vp), ("next_eps", f32), ("next_dtype", i32), ("yn", vp), ("meann", vp), ("rstdn", vp),
+        ("n1w", vp), ("n1b", vp), ("n2w", vp), ("n2b", vp), ("wqkv", vp), ("wproj", vp), ("w1", vp), ("w2", vp),
+        ("bqkv", vp), ("bproj", vp), ("b1", vp), ("b2", vp),
+    ]
+
+
+class BlockBwdArgs(C.Structure):
+    """struct dinox_block_bwd_args (include/dinox.h)."""
+    _fields_ = [
+        ("V", i64), ("N", i64), ("D", i32), ("H", i32), ("heads", i32), ("reserved", i32),
+        ("g", vp), ("g_lowp", vp), ("g_lowp_buf", vp),
+        ("x0", vp), ("x1", vp), ("xn1", vp), ("xn2", vp), ("qkv", vp), ("o", vp), ("lse", vp), ("pre", vp), ("act", vp),
+        ("mean1", vp), ("rstd1", vp), ("mean2", vp), ("rstd2", vp), ("n1w", vp), ("n2w", vp),
+        ("wqkv_t", vp), ("wproj_t", vp), ("w1_t", vp), ("w2_t", vp),
+        ("dwqkv", vp), ("dbqkv", vp), ("dwproj", vp), ("dbproj", vp), ("dw1", vp), ("db1", vp), ("dw2", vp), ("db2", vp),
+        ("dn1w", vp), ("dn1b", vp), ("dn2w", vp), ("dn2b", vp),
+        ("dpre", vp), ("dxn2", vp), ("d_o", vp), ("dqkv", vp), ("dxn1", vp), ("g1", vp), ("g1_lowp", vp), ("g0_lowp", vp),
+        ("attn_ws", vp), ("ln_ws", vp), ("tn_ws", vp), ("tn_ws_bytes", i64),
+    ]
+
+
 # name -> (restype, argtypes); order and types mirror include/dinox.h exactly.
 SIGNATURES = {
     "dinox_version": (i32, []),
@@ -87,6 +114,10 @@ SIGNATURES = {
     "dinox_zero": (i32, [vp, i64, vp]),
     "dinox_gelu_fwd": (i32, [vp, vp, i64, vp]),
     "dinox_gelu_bwd": (i32, [vp, vp, vp, i64, vp]),
+    "dinox_block_forward": (i32, [C.POINTER(BlockFwdArgs), vp]),
+    "dinox_block_backward": (i32, [C.POINTER(BlockBwdArgs), vp]),
+    "dinox_gemm_timer_start": (i32, [i32]),
+    "dinox_gemm_timer_stop": (i64, [C.c_char_p, i64]),
 }
 
 

@@ -21,7 +21,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import BF16, EPI_ACCUM, EPI_AUXGRAD, EPI_BIAS, EPI_DGELU, EPI_GELU, EPI_RESIDUAL, F32, GemmArgs, check, lib
+from ._lib import BF16, EPI_ACCUM, EPI_AUXGRAD, EPI_BIAS, EPI_DGELU, EPI_GELU, EPI_RESIDUAL, F32, BlockBwdArgs, BlockFwdArgs, GemmArgs, check, lib
 
 Tensor = torch.Tensor
 _OVERRIDE: list = []
@@ -82,75 +82,79 @@ def _c(t: Tensor) -> Tensor:
 
 
 class GemmTimer:
-    """Optional timing of dinox_gemm launches with HIP events recorded on the launch stream (bench.py installs one over
-    its timed region to price the dominant kernel against its roofline).  Keyed by the kernel the dispatcher picks
-    (dinox_gemm_kernel_name).  Every launch is COUNTED (launches, algorithmic flops and bytes); one launch in `every` is
-    TIMED -- an event pair per launch costs the timed region 2.3 % at bs 256 (40.94 vs 40.00 ms) (two marker packets around each of ~300
-    launches per step keep the next kernel from starting under the previous one's tail), which a 1-in-16 sample brings
-    to nothing measurable (40.02 ms).  The pick is a fixed multiplicative hash of the launch counter, so every position of the step is reached
-    over a few steps; a family's time is the sum over its shapes of (mean timed duration of the shape) x (its launches)."""
+    """Timing of dinox_gemm launches with HIP events recorded on the launch stream, INSIDE the library (dinox_gemm_timer_start / _stop:
+    the launches that dinox_block_forward / _backward issue from C are seen too; bench.py runs one over its timed region to price the
+    dominant kernel against its roofline).  Keyed by the kernel the dispatcher picks.  Every launch is COUNTED (launches, algorithmic
+    flops and bytes); one launch in `every` is TIMED -- an event pair per launch costs the timed region 2.3 % at bs 256 (40.94 vs 40.00 ms:
+    two marker packets around each of ~300 launches per step keep the next kernel from starting under the previous one's tail), which a
+    1-in-16 sample brings to nothing measurable (40.02 ms).  The pick is a fixed multiplicative hash of the launch counter, so every
+    position of the step is reached over a few steps; a family's time is the sum over its shapes of (mean timed duration of the shape)
+    x (its launches).  One timer per process; not under graph capture."""
 
     def __init__(self, every: int = 16) -> None:
         self.every = max(1, int(every))
-        self.n = 0
-        self.shapes: dict = {}   # (kernel, M, N, K, batch, epilogue) -> [launches, flops, bytes, [(e0, e1), ...]]
-        self.pool = []
+        self.text = ""
 
-    def _event(self):
-        return self.pool.pop() if self.pool else torch.cuda.Event(enable_timing=True)
+    def start(self) -> None:
+        check(lib.dinox_gemm_timer_start(self.every), "dinox_gemm_timer_start")
+
+    def stop(self) -> None:
+        """Synchronises the recorded events and collects the per-shape records."""
+        buf = C.create_string_buffer(1 << 20)
+        n = lib.dinox_gemm_timer_stop(buf, len(buf))
+        if n < 0:
+            raise RuntimeError("dinox_gemm_timer_stop: record buffer too small")
+        self.text += buf.value.decode()
+
+    def __enter__(self):
+        self.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.stop()
+        return False
 
     @staticmethod
-    def algorithmic_bytes(g) -> float:
+    def algorithmic_bytes(M, N, K, batch, epilogue, in_dtype, out_dtype, has_aux, shared_b) -> float:
         """HBM bytes one launch has to move if every operand and result crosses the memory interface exactly once:
         A (M x K) and B (N x K, once if shared by the batch) in the input dtype, C (M x N) in the output dtype, plus the
         epilogue's extra tensors -- the fp32 residual read, the GELU' side tensor written (GELU) or read (DGELU), C read back
         under ACCUM."""
-        isz = 2 if g.in_dtype == BF16 else 4
-        osz = 2 if g.out_dtype == BF16 else 4
-        mn = float(g.M) * g.N * g.batch
-        b = float(g.M) * g.K * g.batch * isz + float(g.N) * g.K * isz * (g.batch if g.strideB else 1) + mn * osz
-        if g.epilogue & EPI_RESIDUAL:
+        isz = 2 if in_dtype == BF16 else 4
+        osz = 2 if out_dtype == BF16 else 4
+        mn = float(M) * N * batch
+        b = float(M) * K * batch * isz + float(N) * K * isz * (1 if shared_b else batch) + mn * osz
+        if epilogue & EPI_RESIDUAL:
             b += mn * 4
-        if g.aux and (g.epilogue & (EPI_GELU | EPI_DGELU)):
+        if has_aux and (epilogue & (EPI_GELU | EPI_DGELU)):
             b += mn * osz
-        if g.epilogue & EPI_ACCUM:
+        if epilogue & EPI_ACCUM:
             b += mn * 4
         return b
 
-    def launch(self, g, stream) -> None:
-        name = lib.dinox_gemm_kernel_name(C.byref(g)).decode()
-        rec = self.shapes.setdefault((name, g.M, g.N, g.K, g.batch, g.epilogue), [0, 0.0, 0.0, []])
-        rec[0] += 1
-        rec[1] += 2.0 * g.M * g.N * g.K * g.batch
-        rec[2] += self.algorithmic_bytes(g)
-        self.n += 1
-        if self.every == 1 or ((self.n * 2654435761) & 0xFFFFFFFF) * self.every >> 32 == 0:
-            e0, e1 = self._event(), self._event()
-            e0.record()
-            check(lib.dinox_gemm(C.byref(g), stream), "dinox_gemm")
-            e1.record()
-            rec[3].append((e0, e1))
-        else:
-            check(lib.dinox_gemm(C.byref(g), stream), "dinox_gemm")
-
     def summary(self) -> dict:
-        """{kernel: {"launches", "timed", "flops", "bytes", "ms"}} -- call after a device synchronise.  "ms" is the family's
-        time over ALL its launches, estimated from the timed ones (see the class docstring)."""
+        """{kernel: {"launches", "timed", "flops", "bytes", "ms"}} -- after stop().  "ms" is the family's time over ALL its launches,
+        estimated from the timed ones (see the class docstring)."""
         out: dict = {}
         untimed = []
-        for (name, *_), (launches, fl, by, evs) in self.shapes.items():
+        for line in self.text.splitlines():
+            f = line.split()
+            if len(f) != 13:
+                continue
+            name = f[0]
+            M, N, K, batch, epi, idt, odt, aux, shb, launches, timed = (int(v) for v in f[1:12])
+            ms = float(f[12])
+            fl = 2.0 * M * N * K * batch * launches
+            by = self.algorithmic_bytes(M, N, K, batch, epi, idt, odt, aux, shb) * launches
             d = out.setdefault(name, {"launches": 0, "timed": 0, "flops": 0.0, "bytes": 0.0, "ms": 0.0, "_tb": 0.0, "_tms": 0.0})
             d["launches"] += launches
             d["flops"] += fl
             d["bytes"] += by
-            if evs:
-                ms = sum(e0.elapsed_time(e1) for e0, e1 in evs)
-                d["timed"] += len(evs)
-                d["ms"] += ms / len(evs) * launches
-                d["_tb"] += by / launches * len(evs)
+            if timed:
+                d["timed"] += timed
+                d["ms"] += ms / timed * launches
+                d["_tb"] += by / launches * timed
                 d["_tms"] += ms
-                for pair in evs:
-                    self.pool += pair
             else:
                 untimed.append((name, by))
         for name, by in untimed:          # a shape the sample never reached: the family's measured time per algorithmic byte
@@ -161,11 +165,10 @@ class GemmTimer:
             del out[name]
         for d in out.values():
             del d["_tb"], d["_tms"]
-        self.shapes = {}
+        self.text = ""
         return out
 
 
-GEMM_TIMER: Optional[GemmTimer] = None
 TRACE_KERNELS: Optional[list] = None      # tests set this to a list to learn which GEMM kernel each call used
 
 
@@ -248,10 +251,7 @@ def gemm(A: Tensor, B: Tensor, *, transA=False, transB=False, out: Optional[Tens
             g.ws = _p(_tn_workspace(need, A.device))
     if TRACE_KERNELS is not None:
         TRACE_KERNELS.append(lib.dinox_gemm_kernel_name(C.byref(g)).decode())
-    if GEMM_TIMER is not None:
-        GEMM_TIMER.launch(g, _stream())
-    else:
-        check(lib.dinox_gemm(C.byref(g), _stream()), "dinox_gemm")
+    check(lib.dinox_gemm(C.byref(g), _stream()), "dinox_gemm")
     return out
 
 
@@ -867,6 +867,125 @@ def weight_grad(dy: Tensor, x: Tensor, w: Tensor, bias: Optional[Tensor], want_d
     return dw.reshape(w.shape), db
 
 
+_BLOCK_NATIVE = os.environ.get("DINOX_BLOCK_NATIVE", "1") != "0"      # "0": the block node issues its launches one by one from Python (A/B, tests)
+
+
+def _block_native_ok(dt: torch.dtype, x0: Tensor, wqkv: Tensor) -> bool:
+    """May this block run as ONE call into the library (dinox_block_forward / _backward, csrc/block.hip)?  bf16 throughput mode only (the
+    fp32 parity mode composes full-size attention from several launches on the host), nobody listening to individual launches, and the
+    weight-gradient side stream off (its products are enqueued from Python)."""
+    return _BLOCK_NATIVE and dt == torch.bfloat16 and x0.is_cuda and TRACE_KERNELS is None and not dw_stream.enabled
+
+
+def _block_forward_native(ctx, x0, n1w, n1b, wqkv, bqkv, wproj, bproj, n2w, n2b, w1, b1, w2, b2, heads, eps, pre_ln, next_ln, train):
+    """BlockFn.forward through dinox_block_forward: the same kernels in the same order, one foreign call."""
+    dt = torch.bfloat16
+    V, N, D = x0.shape
+    M, H = V * N, w1.shape[0]
+    dev = x0.device
+    bf = lambda *shape: torch.empty(shape, dtype=torch.bfloat16, device=dev)
+    f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+    if pre_ln is None:
+        xn1, mean1, rstd1 = bf(V, N, D), f32(M), f32(M)
+    else:
+        xn1, mean1, rstd1 = pre_ln
+    qkv, o, lse = bf(M, 3 * D), bf(V, N, D), f32(V, heads, N)
+    x1, xn2, mean2, rstd2 = f32(M, D), bf(M, D), f32(M), f32(M)
+    act = bf(M, H)
+    pre = bf(M, H) if train else None
+    x2 = f32(V, N, D)
+    nxt = None
+    wops = [weight_operand(w_, dt) for w_ in (wqkv, wproj, w1, w2)]          # (held until the call is enqueued: a per-call cast would otherwise be freed)
+    a = BlockFwdArgs(V=V, N=N, D=D, H=H, heads=heads, train=int(train), fuse_proj_ln=int(rowln_ok(M, D, D, dt)), fuse_fc2_ln=0, eps=eps,
+                     x0=_p(x0), qkv=_p(qkv), o=_p(o), lse=_p(lse), x1=_p(x1), xn2=_p(xn2), mean2=_p(mean2), rstd2=_p(rstd2), act=_p(act), pre=_p(pre),
+                     x2=_p(x2), n1w=_p(n1w), n1b=_p(n1b), n2w=_p(n2w), n2b=_p(n2b), wqkv=_p(wops[0]), wproj=_p(wops[1]), w1=_p(wops[2]), w2=_p(wops[3]),
+                     bqkv=_p(bqkv), bproj=_p(bproj), b1=_p(b1), b2=_p(b2))
+    if pre_ln is None:
+        a.xn1, a.mean1, a.rstd1 = _p(xn1), _p(mean1), _p(rstd1)
+    else:
+        a.xn1_in, a.mean1_in, a.rstd1_in = _p(xn1), _p(mean1), _p(rstd1)
+    if next_ln is not None:
+        ydt = next_ln[3] or dt
+        yn, mn, rn = torch.empty((V, N, D), dtype=ydt, device=dev), f32(M), f32(M)
+        a.next_g, a.next_b, a.next_eps, a.next_dtype = _p(next_ln[0]), _p(next_ln[1]), next_ln[2], _code(ydt)
+        a.yn, a.meann, a.rstdn = _p(yn), _p(mn), _p(rn)
+        a.fuse_fc2_ln = int(rowln_ok(M, D, H, dt))
+        nxt = (yn, mn, rn)
+    check(lib.dinox_block_forward(C.byref(a), _stream()), "dinox_block_forward")
+    if train:
+        ctx.save_for_backward(x0, x1, xn1, xn2, qkv, o, lse, pre, act, mean1, rstd1, mean2, rstd2, n1w, n2w, wqkv, wproj, w1, w2,
+                              bqkv, bproj, b1, b2, n1b, n2b)
+        ctx.dt, ctx.heads, ctx.shape, ctx.native = dt, heads, (V, N, D), True
+        grad_sink.use(wqkv, bqkv, wproj, bproj, w1, b1, w2, b2, n1w, n1b, n2w, n2b)
+    if next_ln is None:
+        return x2
+    ctx.mark_non_differentiable(*nxt)
+    return (x2,) + nxt
+
+
+_BLOCK_TN_WS: dict = {}
+
+
+def _block_tn_ws_bytes(M: int, D: int, H: int) -> int:
+    """Workspace the four dW products of a block need for their deterministic split-K reduction (the largest of them), asked of the
+    library once per shape (dinox_gemm_ws_bytes looks at shapes and pointer alignment only)."""
+    key = (M, D, H)
+    hit = _BLOCK_TN_WS.get(key)
+    if hit is None:
+        hit = 0
+        for n_out, n_in in ((D, H), (H, D), (D, D), (3 * D, D)):
+            g = GemmArgs(A=0x1000, B=0x1000, C=0x1000, M=n_out, N=n_in, K=M, lda=n_out, ldb=n_in, ldc=n_in, batch=1, strideA=0, strideB=0, strideC=n_out * n_in,
+                         transA=1, transB=1, in_dtype=BF16, out_dtype=F32, epilogue=EPI_ACCUM, alpha=1.0, bias=None, residual=None, ldr=n_in, aux=None,
+                         ldaux=n_in, colsum=0x1000, ws=0x1000)
+            hit = max(hit, int(lib.dinox_gemm_ws_bytes(C.byref(g))))
+        _BLOCK_TN_WS[key] = hit
+    return hit
+
+
+def _block_backward_native(ctx, g: Tensor, saved):
+    """BlockFn.backward through dinox_block_backward -- when every parameter gradient of the block goes straight into the gradient arena
+    (the training engine's registration); otherwise None and the composed path takes over.  `saved` = ctx.saved_tensors, unpacked by the
+    caller (under torch.utils.checkpoint they may be unpacked only once)."""
+    (x0, x1, xn1, xn2, qkv, o, lse, pre, act, mean1, rstd1, mean2, rstd2, n1w, n2w, wqkv, wproj, w1, w2, bqkv, bproj, b1, b2,
+     n1b, n2b) = saved
+    slots = [grad_sink.lookup(t) for t in (wqkv, bqkv, wproj, bproj, w1, b1, w2, b2, n1w, n1b, n2w, n2b)]
+    have = [t is not None for t in (wqkv, bqkv, wproj, bproj, w1, b1, w2, b2, n1w, n1b, n2w, n2b)]
+    if any(h and s is None for h, s in zip(have, slots)) or not all(have[i] for i in (0, 2, 4, 6, 8, 9, 10, 11)):
+        return None
+    dt, heads = torch.bfloat16, ctx.heads
+    V, N, D = ctx.shape
+    M, H = V * N, w1.shape[0]
+    dev = g.device
+    bf = lambda *shape: torch.empty(shape, dtype=torch.bfloat16, device=dev)
+    g_lp = lowp_cache.take(g)
+    g1 = torch.empty((V, N, D), dtype=torch.float32, device=dev)
+    g0_lp = bf(V, N, D)
+    gp = lambda sl: None if sl is None else sl[1].grad.data_ptr()
+    tn_ws = _tn_workspace(max(_block_tn_ws_bytes(M, D, H), 1), dev)
+    # scratch of the call: every tensor is HELD until the call has been enqueued (a temporary freed inside the argument list would hand
+    # its memory to the next allocation of the same list: dpre, dxn2, ... would alias)
+    scratch = dict(dpre=bf(M, H), dxn2=bf(M, D), d_o=bf(M, D), dqkv=bf(M, 3 * D), dxn1=bf(M, D), g1_lowp=bf(M, D),
+                   g_lowp_buf=None if g_lp is not None else bf(M, D),
+                   attn_ws=torch.empty(lib.dinox_attention_bwd_ws_bytes(V, N, heads), dtype=torch.uint8, device=dev),
+                   ln_ws=torch.empty(lib.dinox_layernorm_bwd_ws_bytes(M, D), dtype=torch.uint8, device=dev))
+    wts = [weight_operand(w_, dt, transposed=True) for w_ in (wqkv, wproj, w1, w2)]
+    a = BlockBwdArgs(V=V, N=N, D=D, H=H, heads=heads, g=_p(g), g_lowp=_p(g_lp), g_lowp_buf=_p(scratch["g_lowp_buf"]),
+                     x0=_p(x0), x1=_p(x1), xn1=_p(xn1), xn2=_p(xn2), qkv=_p(qkv), o=_p(o), lse=_p(lse), pre=_p(pre), act=_p(act), mean1=_p(mean1),
+                     rstd1=_p(rstd1), mean2=_p(mean2), rstd2=_p(rstd2), n1w=_p(n1w), n2w=_p(n2w),
+                     wqkv_t=_p(wts[0]), wproj_t=_p(wts[1]), w1_t=_p(wts[2]), w2_t=_p(wts[3]),
+                     dwqkv=gp(slots[0]), dbqkv=gp(slots[1]), dwproj=gp(slots[2]), dbproj=gp(slots[3]), dw1=gp(slots[4]), db1=gp(slots[5]),
+                     dw2=gp(slots[6]), db2=gp(slots[7]), dn1w=gp(slots[8]), dn1b=gp(slots[9]), dn2w=gp(slots[10]), dn2b=gp(slots[11]),
+                     dpre=_p(scratch["dpre"]), dxn2=_p(scratch["dxn2"]), d_o=_p(scratch["d_o"]), dqkv=_p(scratch["dqkv"]), dxn1=_p(scratch["dxn1"]),
+                     g1=_p(g1), g1_lowp=_p(scratch["g1_lowp"]), g0_lowp=_p(g0_lp), attn_ws=_p(scratch["attn_ws"]), ln_ws=_p(scratch["ln_ws"]),
+                     tn_ws=_p(tn_ws), tn_ws_bytes=tn_ws.numel())
+    check(lib.dinox_block_backward(C.byref(a), _stream()), "dinox_block_backward")
+    for sl in slots:
+        if sl is not None:
+            grad_sink.ready(sl)
+    lowp_cache.put(g1, g0_lp)
+    return (g1,) + (None,) * 16
+
+
 class BlockFn(torch.autograd.Function):
     """One pre-norm transformer block as a single autograd node (reference zoo/arch.py:94-97 with
     Attention :43-54 and Mlp :75-76 inlined):  x1 = x0 + proj(attn(norm1(x0)));  x2 = x1 + fc2(gelu(fc1(norm2(x1)))).
@@ -889,6 +1008,9 @@ class BlockFn(torch.autograd.Function):
         V, N, D = x0.shape
         M = V * N
         train = any(ctx.needs_input_grad)
+        if _block_native_ok(dt, x0, wqkv):
+            return _block_forward_native(ctx, x0, n1w, n1b, wqkv, bqkv, wproj, bproj, n2w, n2b, w1, b1, w2, b2, heads, eps, pre_ln, next_ln, train)
+        ctx.native = False
         if pre_ln is None:
             xn1, mean1, rstd1 = layernorm_fwd(x0, n1w, n1b, dt, eps)
         else:
@@ -936,6 +1058,11 @@ class BlockFn(torch.autograd.Function):
         dev = g.device
         g = _c(g if g.dtype == torch.float32 else g.float())
         bf = dt == torch.bfloat16
+        if ctx.native:
+            native = _block_backward_native(ctx, g, (x0, x1, xn1, xn2, qkv, o, lse, pre, act, mean1, rstd1, mean2, rstd2, n1w, n2w, wqkv, wproj, w1, w2,
+                                                     bqkv, bproj, b1, b2, n1b, n2b))
+            if native is not None:
+                return native
 
         def wt(w):      # W^T operand for dX = dY . W
             return (w.detach(), dict(transB=True)) if not bf else (weight_operand(w, dt, transposed=True), {})

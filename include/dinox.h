@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DINOX_ABI_VERSION 2
+#define DINOX_ABI_VERSION 3   /* 3: + dinox_block_forward / _backward, dinox_gemm_timer_* (additive) */
 
 /* dtype codes */
 #define DINOX_F32 0
@@ -319,6 +319,79 @@ int dinox_zero(void* p, int64_t bytes, void* stream);
 /* Elementwise helpers used by the host-side modules: y = gelu_erf(x) / dx = dy * gelu_erf'(x) (fp32). */
 int dinox_gelu_fwd(const float* x, float* y, int64_t n, void* stream);
 int dinox_gelu_bwd(const float* dy, const float* x, float* dx, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * One pre-norm transformer block per call (bf16 throughput mode) -- the launch SEQUENCE of zoo/arch.py:94-97 with Attention :43-54 and
+ * Mlp :75-76 inlined, enqueued by the library instead of by ~13 (forward) / ~15 (backward) calls from the host language:
+ *     x1 = x0 + proj(attention(qkv(norm1(x0))));   x2 = x1 + fc2(gelu(fc1(norm2(x1))))
+ * Same kernels, same order, same results as the entries above called one by one (LayerNorm, dinox_gemm with its fused epilogues,
+ * dinox_attention_*, dinox_linear_residual_ln); still no allocation, no synchronisation, hipGraph-capturable, re-entrant: every tensor,
+ * the saved activations of the backward pass and all workspaces are the caller's.  What it buys is host time: one foreign call per
+ * block instead of one per launch (Python: 24 ms of enqueue per ViT-S bs-256 step before), under data parallelism and
+ * gradient accumulation too.  All activations are row-major [V*N, .]; bf16 tensors are operands of the next product, fp32 ones the
+ * residual stream, the statistics and the gradients.
+ * forward:  xn1_in (+ mean1_in, rstd1_in) non-NULL = norm1(x0) was already produced by the previous block's epilogue; then xn1 /
+ *           mean1 / rstd1 are not written.  fuse_proj_ln / fuse_fc2_ln: run the product and the LayerNorm behind it as ONE launch
+ *           (dinox_linear_residual_ln; needs dinox_linear_residual_ln_ok).  next_g non-NULL: also return yn = LayerNorm(x2; next_g,
+ *           next_b, next_eps) in next_dtype with its statistics (the next block's norm1, or the model's final norm).
+ *           pre non-NULL (training): fc1 also writes gelu'(pre-activation) there (the DINOX_EPI_AUXGRAD side tensor).
+ * backward: g = d loss / d x2 (fp32), g_lowp = its bf16 copy (NULL: cast here into g_lowp_buf).  Weight operands are the TRANSPOSED
+ *           bf16 images W^T [in][out] (dX = dY . W as an NT product).  Parameter gradients are ACCUMULATED into dwqkv .. dn2b (slices
+ *           of a gradient arena).  Scratch: dpre [M,H], dxn2 / d_o / dxn1 [M,D], dqkv [M,3D] bf16; g1 [M,D] fp32 and g1_lowp bf16.
+ *           Outputs: g0 = d loss / d x0 written IN PLACE of g1 (same buffer), g0_lowp its bf16 copy.
+ *           attn_ws: dinox_attention_bwd_ws_bytes; ln_ws: dinox_layernorm_bwd_ws_bytes(M, D) (used twice, in stream order);
+ *           tn_ws / tn_ws_bytes: workspace of the deterministic dW products (>= the largest dinox_gemm_ws_bytes of the four).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct dinox_block_fwd_args {
+  int64_t V, N;                        /* views, tokens per view: M = V * N rows */
+  int32_t D, H, heads;                 /* width, MLP hidden width, attention heads */
+  int32_t train;                       /* != 0: `pre` receives the GELU' side tensor */
+  int32_t fuse_proj_ln, fuse_fc2_ln;
+  float eps;                           /* of norm1 / norm2 */
+  const float* x0;
+  const void* xn1_in; const float* mean1_in; const float* rstd1_in;
+  void* xn1; float* mean1; float* rstd1;
+  void* qkv; void* o; float* lse;
+  float* x1; void* xn2; float* mean2; float* rstd2;
+  void* act; void* pre;
+  float* x2;
+  const float* next_g; const float* next_b; float next_eps; int32_t next_dtype;
+  void* yn; float* meann; float* rstdn;
+  const float *n1w, *n1b, *n2w, *n2b;
+  const void *wqkv, *wproj, *w1, *w2;  /* bf16 [3D,D], [D,D], [H,D], [D,H] */
+  const float *bqkv, *bproj, *b1, *b2; /* fp32 or NULL */
+} dinox_block_fwd_args;
+
+typedef struct dinox_block_bwd_args {
+  int64_t V, N;
+  int32_t D, H, heads;
+  int32_t reserved;
+  const float* g; const void* g_lowp; void* g_lowp_buf;
+  /* saved by the forward */
+  const float* x0; const float* x1; const void* xn1; const void* xn2; const void* qkv; const void* o; const float* lse;
+  const void* pre; const void* act; const float *mean1, *rstd1, *mean2, *rstd2;
+  const float *n1w, *n2w;
+  const void *wqkv_t, *wproj_t, *w1_t, *w2_t;   /* bf16 W^T: [D,3D], [D,D], [D,H], [H,D] */
+  /* gradient arena slices (accumulated into); bias gradients may be NULL */
+  float *dwqkv, *dbqkv, *dwproj, *dbproj, *dw1, *db1, *dw2, *db2, *dn1w, *dn1b, *dn2w, *dn2b;
+  /* scratch and outputs */
+  void* dpre; void* dxn2; void* d_o; void* dqkv; void* dxn1;
+  float* g1; void* g1_lowp; void* g0_lowp;
+  void* attn_ws; void* ln_ws; void* tn_ws; int64_t tn_ws_bytes;
+} dinox_block_bwd_args;
+
+int dinox_block_forward(const dinox_block_fwd_args* args, void* stream);
+int dinox_block_backward(const dinox_block_bwd_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Per-launch timing of dinox_gemm (diagnostic; bench.py's roofline object).  Between start and stop every dinox_gemm launch -- also
+ * the ones dinox_block_* issue -- is counted per (kernel, shape, epilogue), and one launch in `every` (a fixed hash of the launch
+ * counter) is bracketed by a HIP event pair on its stream.  stop synchronises those events and writes one text line per shape into
+ * buf:  "<kernel> M N K batch epilogue in_dtype out_dtype has_aux shared_b launches timed ms_timed\n"  and returns the bytes written
+ * (-1: buffer too small).  Not for use under graph capture; one timer per process.
+ * ------------------------------------------------------------------------------------------ */
+int dinox_gemm_timer_start(int every);
+int64_t dinox_gemm_timer_stop(char* buf, int64_t buflen);
 
 #ifdef __cplusplus
 }

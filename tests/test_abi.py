@@ -46,7 +46,7 @@ def test_ctypes_table_matches_header():
 
 def test_version_and_error_plumbing():
     from dinox import _lib
-    assert _lib.lib.dinox_version() == 2
+    assert _lib.lib.dinox_version() == 3
     # argument validation happens on the host before any launch: safe without a GPU
     rc = _lib.lib.dinox_layernorm_fwd(None, None, None, None, None, None, 4, 8, 1e-5, 0, None)
     assert rc == -1 and "null pointer" in _lib.last_error()
@@ -63,6 +63,30 @@ def test_gemm_args_struct_layout():
     assert GemmArgs.ws.offset == ctypes.sizeof(GemmArgs) - 8
     assert GemmArgs.alpha.offset == 13 * 8 + 5 * 4
     assert GemmArgs.bias.offset == 13 * 8 + 24
+
+
+def test_block_args_struct_layout(tmp_path):
+    """The ctypes mirrors of dinox_block_fwd_args / dinox_block_bwd_args against the C structs themselves: a small C program that
+    includes include/dinox.h prints sizeof / offsetof, compiled with the host compiler (a mismatch would hand the kernels garbage
+    pointers)."""
+    import shutil
+    import subprocess
+    from dinox._lib import BlockBwdArgs as B, BlockFwdArgs as F
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        pytest.skip("no host C compiler")
+    src = tmp_path / "sz.c"
+    src.write_text("#include <stdio.h>\n#include <stddef.h>\n#include \"dinox.h\"\nint main(void){\n"
+                   "printf(\"%zu %zu %zu %zu %zu %zu\\n\", sizeof(dinox_block_fwd_args), offsetof(dinox_block_fwd_args, x0), offsetof(dinox_block_fwd_args, eps),"
+                   " offsetof(dinox_block_fwd_args, next_eps), offsetof(dinox_block_fwd_args, yn), offsetof(dinox_block_fwd_args, b2));\n"
+                   "printf(\"%zu %zu %zu %zu %zu\\n\", sizeof(dinox_block_bwd_args), offsetof(dinox_block_bwd_args, g), offsetof(dinox_block_bwd_args, dwqkv),"
+                   " offsetof(dinox_block_bwd_args, g0_lowp), offsetof(dinox_block_bwd_args, tn_ws_bytes));\nreturn 0;}\n")
+    exe = tmp_path / "sz"
+    subprocess.run([cc, "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = subprocess.run([str(exe)], check=True, stdout=subprocess.PIPE).stdout.decode().split()
+    want = [ctypes.sizeof(F), F.x0.offset, F.eps.offset, F.next_eps.offset, F.yn.offset, F.b2.offset,
+            ctypes.sizeof(B), B.g.offset, B.dwqkv.offset, B.g0_lowp.offset, B.tn_ws_bytes.offset]
+    assert [int(v) for v in got] == want
 
 
 def test_gemm_dispatch_by_shape(monkeypatch):

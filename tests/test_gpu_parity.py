@@ -443,6 +443,46 @@ def test_block_fused_node_matches_composed_ops(dx, mode):
         assert rel_l2(outs[0][2][n], outs[1][2][n]) < tol, n
 
 
+@pytest.mark.parametrize("accum,ckpt", [(1, False), (2, False), (1, True)])
+def test_native_block_sequencing_changes_no_bit(dx, accum, ckpt):
+    """dinox_block_forward / dinox_block_backward (csrc/block.hip: one C-ABI call per transformer block instead of ~13 / ~15 from Python)
+    enqueue the same kernels in the same order on the same buffers' worth of data: two optimiser steps of a ViT-S-width model through
+    them must end BIT-identical to the same steps with the block node issuing every launch itself (ops._BLOCK_NATIVE = False) --
+    weights, Adam moments, teacher, centre and the logged scalars; also under gradient accumulation and --grad-checkpoint."""
+    ops, arch = dx
+    from dinox.engine import StepHyperParams, TrainEngine
+    kw = dict(img_size=112, patch=16, dim=384, depth=3, heads=6, num_registers=4, scale_aware=True, use_grad_checkpoint=ckpt)
+    g = torch.Generator().manual_seed(31)
+    B = 12
+    batch = torch.randn(2 * B, 3, 112, 112, generator=g).to(DEV)
+    sp = (torch.rand(2 * B, 3, generator=g) + 0.5).to(DEV)
+
+    def run(native):
+        torch.manual_seed(5)
+        s_ = arch.DinoStudentTeacher(arch.PatchViT(**kw), 512)
+        torch.nn.init.xavier_uniform_(s_.backbone.scale_embed.mlp[2].weight)
+        t_ = arch.DinoStudentTeacher(arch.PatchViT(**kw), 512)
+        t_.load_state_dict(s_.state_dict())
+        was = ops._BLOCK_NATIVE
+        ops._BLOCK_NATIVE = native
+        try:
+            eng = TrainEngine(s_.to(DEV), t_.to(DEV), 512, StepHyperParams(lr=1e-3, warmup_steps=1, max_steps=10, ema=0.99, koleo_weight=0.1),
+                              amp_dtype=torch.bfloat16, accumulation_steps=accum)
+            s_.train()
+            for _ in range(2 * accum):
+                eng.step(batch, sp)
+            sc = eng.scalars()
+        finally:
+            ops._BLOCK_NATIVE = was
+        return eng.flat_p.clone(), eng.adam_m.clone(), eng.adam_v.clone(), eng.flat_t.clone(), eng.center.clone(), sc
+
+    a, b = run(True), run(False)
+    for x, y in zip(a[:5], b[:5]):
+        assert torch.equal(x, y)
+    assert a[5] == b[5], (a[5], b[5])
+    assert math.isfinite(a[5]["loss"]) and a[5]["grad_norm"] > 0
+
+
 def test_vit_plain_golden_no_registers(dx):
     ops, arch = dx
     g = load_golden("vit_plain.npz")
@@ -1843,13 +1883,10 @@ def test_gemm_timer_samples_launches_and_prices_families(dx):
     out = {}
     for every in (1, 4):
         t = ops.GemmTimer(every=every)
-        ops.GEMM_TIMER = t
-        try:
+        with t:                                                      # dinox_gemm_timer_start .. _stop: the library brackets its own launches
             for _ in range(40):
                 h = ops.gemm(a, w1)
                 y = ops.gemm(h, w2)
-        finally:
-            ops.GEMM_TIMER = None
         torch.cuda.synchronize()
         assert torch.equal(h, ref1) and torch.equal(y, ref2)
         out[every] = t.summary()

@@ -35,9 +35,29 @@ __device__ __forceinline__ void vw_taps(int i, float scale, float support, int i
   xsize = min((int)(center + support + 0.5f), in_size) - xmin;
 }
 
+// Where output pixel (c, oy, ox) of view v goes.  LAYOUT 0: the fp32 image batch [V][3][S][S].  LAYOUT 1 / 2: the patch-embed
+// operand itself, u[(v P + (oy / p) g + ox / p)][c p^2 + (oy % p) p + ox % p] with g = S / p, row stride ld, in bf16 (1) or fp32 (2) --
+// what dinox_patch_unfold would make of the image batch (tokens.hip), without the 4 B/pixel image round trip through HBM.  With
+// p = 16 a tile is one channel of one patch: 256 consecutive operand elements per workgroup.
+template <int LAYOUT>
+struct vw_out {
+  void* base; int S, p, g, ld;
+  __device__ __forceinline__ void put(int v, int c, int oy, int ox, float val) const {
+    if (LAYOUT == 0) {
+      ((float*)base)[(((int64_t)v * 3 + c) * S + oy) * (int64_t)S + ox] = val;
+    } else {
+      const int gy = oy / p, gx = ox / p;
+      const int64_t o = ((int64_t)v * g * g + gy * g + gx) * (int64_t)ld + (c * p + (oy - gy * p)) * p + (ox - gx * p);
+      if (LAYOUT == 1) ((bf16_t*)base)[o] = f32_to_bf16(val);
+      else ((float*)base)[o] = val;
+    }
+  }
+};
+
 // vi[v] = {element offset of the stack in raw, H, W, top, left, h, w, flip};  vf[v] = {wmin, wden}
+template <int LAYOUT>
 __global__ __launch_bounds__(VW_THREADS) void slice_views_kernel(const unsigned short* __restrict__ raw, const int64_t* __restrict__ vi,
-                                                               const float* __restrict__ vf, float* __restrict__ out, int S,
+                                                               const float* __restrict__ vf, vw_out<LAYOUT> out, int S,
                                                                int tiles, int F, int MAXT) {
   extern __shared__ float vw_smem[];
   float* src = vw_smem;                  // [F][F]   windowed footprint
@@ -104,10 +124,9 @@ __global__ __launch_bounds__(VW_THREADS) void slice_views_kernel(const unsigned 
   }
   const int fw = fx1 - fx0, fh = fy1 - fy0;
   bad |= fw > F || fh > F;
-  float* o_plane = out + (((int64_t)v * 3 + c) * S) * S;
   if (bad) {                                                   // never silently wrong
     const int oy = oy0 + t / VW_T, ox = ox0 + t % VW_T;
-    if (oy < S && ox < S) o_plane[(int64_t)oy * S + ox] = __builtin_nanf("");
+    if (oy < S && ox < S) out.put(v, c, oy, ox, __builtin_nanf(""));
     return;
   }
   // stage the windowed footprint (HU decode + window, scripts/phase5_big_run.py:519-526)
@@ -141,7 +160,7 @@ __global__ __launch_bounds__(VW_THREADS) void slice_views_kernel(const unsigned 
       const int n = s_n[1][qy], r0 = s_min[1][qy] - fy0;
       float a = 0.f;
       for (int k = 0; k < n; ++k) a += w[k] * strip[(r0 + k) * VW_T + qx];
-      o_plane[(int64_t)oy * S + ox] = (a - mean) / stdv;
+      out.put(v, c, oy, ox, (a - mean) / stdv);
     }
   }
 }
@@ -157,17 +176,39 @@ extern "C" int64_t dinox_slice_views_lds_bytes(int S, int max_crop) {
   return (F * F + F * VW_T + 2 * VW_T * MAXT) * (int64_t)sizeof(float);
 }
 
+template <int LAYOUT>
+static int launch_slice_views(const void* raw_u16, const int64_t* view_i, const float* view_f, vw_out<LAYOUT> out, int V, int S, int max_crop,
+                              void* stream, const char* what) {
+  const double s = (double)max_crop / (double)S, sup = 2.0 * (s > 1.0 ? s : 1.0);
+  const int F = (int)(VW_T * s + 2.0 * sup) + 4, MAXT = (int)(2.0 * sup) + 3;
+  const size_t lds = (size_t)dinox_slice_views_lds_bytes(S, max_crop);
+  DX_REQUIRE(lds <= 150 * 1024, DINOX_EUNSUPPORTED, "%s: a %d-pixel crop down to %d needs %zu B of LDS (limit 150 KiB)", what, max_crop, S, lds);
+  if (int rc = reserve_lds(reinterpret_cast<const void*>(slice_views_kernel<LAYOUT>), lds, what)) return rc;
+  const int tiles = (S + VW_T - 1) / VW_T;
+  hipLaunchKernelGGL(slice_views_kernel<LAYOUT>, dim3((unsigned)(tiles * tiles), 3, (unsigned)V), dim3(VW_THREADS), lds, as_stream(stream),
+                     (const unsigned short*)raw_u16, view_i, view_f, out, S, tiles, F, MAXT);
+  return check_launch(what);
+}
+
 extern "C" int dinox_slice_views(const void* raw_u16, const int64_t* view_i, const float* view_f, float* out, int V, int S, int max_crop,
                                  void* stream) {
   DX_REQUIRE(raw_u16 && view_i && view_f && out, DINOX_EINVAL, "slice_views: null pointer");
   DX_REQUIRE(V > 0 && V <= 65535 && S > 0 && max_crop > 0, DINOX_EINVAL, "slice_views: V=%d S=%d max_crop=%d", V, S, max_crop);
-  const double s = (double)max_crop / (double)S, sup = 2.0 * (s > 1.0 ? s : 1.0);
-  const int F = (int)(VW_T * s + 2.0 * sup) + 4, MAXT = (int)(2.0 * sup) + 3;
-  const size_t lds = (size_t)dinox_slice_views_lds_bytes(S, max_crop);
-  DX_REQUIRE(lds <= 150 * 1024, DINOX_EUNSUPPORTED, "slice_views: a %d-pixel crop down to %d needs %zu B of LDS (limit 150 KiB)", max_crop, S, lds);
-  if (int rc = reserve_lds(reinterpret_cast<const void*>(slice_views_kernel), lds, "slice_views")) return rc;
-  const int tiles = (S + VW_T - 1) / VW_T;
-  hipLaunchKernelGGL(slice_views_kernel, dim3((unsigned)(tiles * tiles), 3, (unsigned)V), dim3(VW_THREADS), lds, as_stream(stream),
-                     (const unsigned short*)raw_u16, view_i, view_f, out, S, tiles, F, MAXT);
-  return check_launch("slice_views");
+  return launch_slice_views<0>(raw_u16, view_i, view_f, vw_out<0>{out, S, 1, S, 0}, V, S, max_crop, stream, "slice_views");
+}
+
+extern "C" int dinox_slice_views_patches(const void* raw_u16, const int64_t* view_i, const float* view_f, void* u, int V, int S, int max_crop,
+                                         int patch, int ld, int out_dtype, void* stream) {
+  DX_REQUIRE(raw_u16 && view_i && view_f && u, DINOX_EINVAL, "slice_views_patches: null pointer");
+  DX_REQUIRE(V > 0 && V <= 65535 && S > 0 && max_crop > 0, DINOX_EINVAL, "slice_views_patches: V=%d S=%d max_crop=%d", V, S, max_crop);
+  DX_REQUIRE(patch > 0 && S % patch == 0 && ld >= 3 * patch * patch, DINOX_EINVAL, "slice_views_patches: S=%d patch=%d ld=%d", S, patch, ld);
+  DX_REQUIRE(out_dtype == DINOX_F32 || out_dtype == DINOX_BF16, DINOX_EINVAL, "slice_views_patches: dtype %d", out_dtype);
+  const int g = S / patch;
+  if (ld > 3 * patch * patch) {          // padded operand (patch 14 in bf16: 588 -> 640 columns): the tail columns are zeros
+    const size_t bytes = (size_t)V * g * g * ld * (out_dtype == DINOX_BF16 ? 2 : 4);
+    DX_REQUIRE(hipMemsetAsync(u, 0, bytes, as_stream(stream)) == hipSuccess, DINOX_EINVAL, "slice_views_patches: memset failed");
+  }
+  if (out_dtype == DINOX_BF16)
+    return launch_slice_views<1>(raw_u16, view_i, view_f, vw_out<1>{u, S, patch, g, ld}, V, S, max_crop, stream, "slice_views_patches");
+  return launch_slice_views<2>(raw_u16, view_i, view_f, vw_out<2>{u, S, patch, g, ld}, V, S, max_crop, stream, "slice_views_patches");
 }

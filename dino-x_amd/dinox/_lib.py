@@ -95,6 +95,7 @@ SIGNATURES = {
     "dinox_gram_normalize_bwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "dinox_slice_views_lds_bytes": (i64, [i32, i32]),
     "dinox_slice_views": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
+    "dinox_slice_views_patches": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "dinox_softmax_rows": (i32, [vp, vp, i64, i32, i32, i64, vp]),
     "dinox_softmax_bwd_rows": (i32, [vp, vp, vp, f32, i64, i32, i32, i64, vp]),
     "dinox_koleo_normalize": (i32, [vp, vp, vp, vp, i64, i32, f32, vp]),

@@ -1252,8 +1252,47 @@ def padded_patch_weight(pw: Tensor, dt: torch.dtype, cols: int) -> Tensor:
     return out
 
 
-def patch_unfold(x: Tensor, patch: int, dt: torch.dtype) -> Tensor:
-    """[V,3,H,W] fp32 -> [V*P, patch_cols(patch, dt)] in dt (shared between student and teacher inside ``unfold_share()`` only)."""
+class PatchOperand:
+    """A batch of views that is ALREADY the patch-embed operand: ``u`` = [V*P, patch_cols(patch, dtype)], made by
+    ``views.make_views(..., patch=p, operand_dtype=dt)`` (dinox_slice_views_patches writes it straight from the u16 stacks).  Stands in
+    for the (V,3,S,S) fp32 image batch wherever the training path takes one -- PatchViT.forward, TrainEngine.step -- and answers
+    the few questions they ask of it (shape, device); ``patch_unfold`` hands out ``u`` itself."""
+
+    def __init__(self, u: Tensor, V: int, size: int, patch: int) -> None:
+        g = size // patch
+        assert size % patch == 0 and u.dim() == 2 and u.shape[0] == V * g * g and u.shape[1] >= 3 * patch * patch, (tuple(u.shape), V, size, patch)
+        self.u, self.patch, self.size = u, patch, size
+        self.shape = torch.Size((V, 3, size, size))
+
+    device = property(lambda self: self.u.device)
+    dtype = property(lambda self: self.u.dtype)
+    is_cuda = property(lambda self: self.u.is_cuda)
+
+    def dim(self) -> int:
+        return 4
+
+    def clone(self) -> "PatchOperand":
+        return PatchOperand(self.u.clone(), self.shape[0], self.size, self.patch)
+
+    def copy_(self, other: "PatchOperand", non_blocking: bool = False) -> "PatchOperand":
+        if not isinstance(other, PatchOperand) or other.patch != self.patch:
+            raise TypeError("a patch-operand batch can only be overwritten by another one of the same patch size")
+        self.u.copy_(other.u, non_blocking=non_blocking)
+        return self
+
+    def record_stream(self, stream) -> None:
+        self.u.record_stream(stream)
+
+
+def patch_unfold(x, patch: int, dt: torch.dtype) -> Tensor:
+    """[V,3,H,W] fp32 -> [V*P, patch_cols(patch, dt)] in dt (shared between student and teacher inside ``unfold_share()`` only).
+    A ``PatchOperand`` is that matrix already."""
+    if isinstance(x, PatchOperand):
+        if x.patch != patch or x.u.dtype != dt or x.u.shape[1] != patch_cols(patch, dt):
+            raise ValueError(f"the batch was unfolded for patch {x.patch} in {x.u.dtype} ({x.u.shape[1]} columns); this model takes "
+                             f"patch {patch} in {dt} ({patch_cols(patch, dt)} columns)")
+        _need_cuda(x.u)
+        return x.u
     _need_cuda(x)
     sharing = _unfold_share.depth > 0
     if sharing:

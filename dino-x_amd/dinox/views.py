@@ -9,6 +9,7 @@ transform stack) and ONE kernel (csrc/views.hip, ``dinox_slice_views``) turns th
 from __future__ import annotations
 
 import math
+import os
 import random
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
@@ -77,17 +78,46 @@ class StackBatch:
                           self.spacing.to(device, non_blocking=non_blocking))
 
     def pin_memory(self) -> "StackBatch":
-        """Called by the DataLoader's pinning thread (pin_memory=True): page-locked copies, so that ``to(device)`` is a true
-        asynchronous DMA instead of a staged copy that blocks the host."""
+        """Called by the DataLoader's pinning thread (pin_memory=True): page-locked memory, so that ``to(device)`` is a true
+        asynchronous DMA instead of a staged copy that blocks the host.  With the workers' shared-memory ring (SHM_RING > 0) the ring
+        buffer ITSELF is page-locked once (hipHostRegister on this process's mapping of it) and handed on as it is: no second host
+        copy of the batch (400 MB per 256 stacks of 512 x 512 -- at 25 batches a second more than one thread can copy).  The
+        DevicePrefetcher bounds the copies in flight so that a worker never rewrites a buffer the DMA engine still reads."""
         if SHM_RING > 0 and self.raw.is_shared():      # (ring only: with a fresh shared tensor per batch this would pin them all down)
             # keep the worker's ring buffer MAPPED in this process: torch finds a shared storage it already holds by its file identity,
             # a dropped one is unmapped and mapped again for the next batch in it (120 MB of page-table faults per batch)
             st = self.raw.untyped_storage()
-            _mapped[st.data_ptr()] = st
-            _mapped.move_to_end(st.data_ptr())
+            key = st.data_ptr()
+            hit = _mapped.get(key)
+            if hit is None or hit[0].nbytes() != st.nbytes():
+                if hit is not None:
+                    _unregister(hit)
+                hit = _mapped[key] = (st, _register(st))
+            _mapped.move_to_end(key)
             while len(_mapped) > 128:
-                _mapped.popitem(last=False)
+                _unregister(_mapped.popitem(last=False)[1])
+            if hit[1] and self.raw.is_pinned():
+                return StackBatch(self.raw, self.offsets, self.shapes, self.views, self.spacing.pin_memory())
         return StackBatch(self.raw.pin_memory(), self.offsets, self.shapes, self.views, self.spacing.pin_memory())
+
+
+def _register(st) -> bool:
+    """Page-lock this process's mapping of a shared storage (False: not possible here -- the caller copies to pinned memory instead)."""
+    if os.environ.get("DINOX_PIN_COPY") or not torch.cuda.is_available():
+        return False
+    try:
+        return int(torch.cuda.cudart().cudaHostRegister(st.data_ptr(), st.nbytes(), 0)) == 0
+    except Exception:
+        return False
+
+
+def _unregister(entry) -> None:
+    st, registered = entry
+    if registered:
+        try:
+            torch.cuda.cudart().cudaHostUnregister(st.data_ptr())
+        except Exception:
+            pass
 
 
 class DevicePrefetcher:
@@ -101,6 +131,7 @@ class DevicePrefetcher:
         self.it = iter(loader)
         self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
         self.ahead = None
+        self._inflight: "collections.deque" = collections.deque()       # events of the copies issued last (see _start)
         self.timing = None           # a list -> (start, end) events of every copy (the training script's DINOX_CLI_PROFILE)
         # (the loader iterator is created HERE -- that draws the loader's base seed from torch's global generator, and the training script
         #  creates it at the same point of its start-up as the reference creates its iterator; the first batch is fetched on first use)
@@ -117,6 +148,11 @@ class DevicePrefetcher:
         if self.stream is None:
             self.ahead = (item.to(self.device), None)
             return
+        # At most two copies in flight: the batch may still sit in a loader worker's ring buffer (StackBatch.pin_memory), and the worker
+        # gets that buffer back SHM_RING of ITS batches later -- by then at least two more of its batches have been handed out here,
+        # i.e. this wait has covered the copy that read it.  (The copy stream holds nothing but these copies: the wait is short.)
+        while len(self._inflight) >= 2:
+            self._inflight.popleft().synchronize()
         with torch.cuda.stream(self.stream):
             if self.timing is not None:
                 e0 = torch.cuda.Event(enable_timing=True)
@@ -126,11 +162,19 @@ class DevicePrefetcher:
             ev.record(self.stream)
             if self.timing is not None:
                 self.timing.append((e0, ev))
+        self._inflight.append(ev)
         self.ahead = (dev, ev)
 
     def next(self) -> StackBatch:
         if not self.run_ahead:                           # (A/B and the draw-order test: fetch, copy and hand out in program order)
-            return self._host_next().to(self.device)
+            dev = self._host_next().to(self.device)
+            if self.device.type == "cuda":               # the same bound on copies in flight (here they queue behind the compute)
+                ev = torch.cuda.Event()
+                ev.record()
+                self._inflight.append(ev)
+                while len(self._inflight) > 2:
+                    self._inflight.popleft().synchronize()
+            return dev
         if self.ahead is None:
             self._start()
         dev, ev = self.ahead
@@ -195,10 +239,13 @@ def collate_stacks(items: Sequence[Tuple[object, Sequence[ViewParams], torch.Ten
     return StackBatch(raw, offsets, shapes, views, torch.stack([it[2] for it in items], 0))
 
 
-def make_views(batch: StackBatch, size: int, out: Optional[torch.Tensor] = None, views: Optional[List[List[ViewParams]]] = None) -> torch.Tensor:
+def make_views(batch: StackBatch, size: int, out: Optional[torch.Tensor] = None, views: Optional[List[List[ViewParams]]] = None,
+               patch: Optional[int] = None, operand_dtype: Optional[torch.dtype] = None):
     """(n_views * B, 3, size, size) fp32 on the device of ``batch.raw``, ordered [view 0 of every sample; view 1 ...] like
     ``torch.cat(views, 0)`` in the reference loop (scripts/phase5_big_run.py:1711).  ``views`` selects a subset of
-    ``batch.views`` (e.g. the global views at one size, the local crops of the multi-crop extension at another)."""
+    ``batch.views`` (e.g. the global views at one size, the local crops of the multi-crop extension at another).
+    With ``patch`` (and ``operand_dtype``: torch.bfloat16 under --amp, else torch.float32) the result is an ``ops.PatchOperand``: the
+    same views written directly as the patch-embed operand [V * (size/patch)^2, patch_cols] -- the image batch is never stored."""
     from . import ops
     from ._lib import check, lib
     raw = batch.raw
@@ -219,6 +266,16 @@ def make_views(batch: StackBatch, size: int, out: Optional[torch.Tensor] = None,
     # run ahead of the device (measured in the training script: 49 ms per step instead of the engine's 38.6)
     vi = torch.tensor(rows_i, dtype=torch.int64).pin_memory().to(dev, non_blocking=True)
     vf = torch.tensor(np.asarray(rows_f, dtype=np.float32)).pin_memory().to(dev, non_blocking=True)
+    if patch is not None:
+        dt = operand_dtype or torch.float32
+        if size % patch:
+            raise ValueError(f"view size {size} is not a multiple of the patch size {patch}")
+        cols = ops.patch_cols(patch, dt)
+        u = out if out is not None else torch.empty((V * (size // patch) ** 2, cols), dtype=dt, device=dev)
+        assert u.shape == (V * (size // patch) ** 2, cols) and u.dtype == dt and u.is_contiguous()
+        check(lib.dinox_slice_views_patches(ops._p(raw), ops._p(vi), ops._p(vf), ops._p(u), V, size, max_crop, patch, cols, ops._code(dt),
+                                            ops._stream()), "dinox_slice_views_patches")
+        return ops.PatchOperand(u, V, size, patch)
     if out is None:
         out = torch.empty((V, 3, size, size), dtype=torch.float32, device=dev)
     else:

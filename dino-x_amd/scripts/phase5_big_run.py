@@ -240,6 +240,7 @@ class PngDataset(torch.utils.data.Dataset):
         self.crop_scale = (crop_scale_min, crop_scale_max)
         self.raw_views = False          # True: __getitem__ returns (u16 stack, view draws, spacing) for the device-side pipeline
         self.local_crops, self.local_scale = 0, (0.05, 0.3)      # multi-crop extension: extra student-only views (DINO's local-crop scale)
+        self.cache = None               # dinox.stackcache.SliceCache (--stack-cache): every PNG is decoded once, then read from a u16 memmap
         self._series_map: dict = {}
         for r in rows:
             self._series_map.setdefault(r.series_dir, {})[r.slice_index] = r.png_path
@@ -249,9 +250,10 @@ class PngDataset(torch.utils.data.Dataset):
         return len(self.rows)
 
     def _read(self, p) -> np.ndarray:
-        from PIL import Image
-        arr = np.array(Image.open(p))
-        return arr[:, :, 0] if arr.ndim == 3 else arr
+        if self.cache is not None:
+            return self.cache.get(p)
+        from dinox.stackcache import decode_png_u16
+        return decode_png_u16(p)
 
     def _stack(self, row: IndexRow) -> list:
         z0, z1 = self._series_minmax.get(row.series_dir, (row.slice_index, row.slice_index))
@@ -581,6 +583,10 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--hip-graph", action="store_true",
                     help="Replay the whole optimiser step as one captured hipGraph after two eager steps (extension; single GPU, "
                          "--accumulation-steps 1): for small batches, where launching ~300 kernels per step costs more than running them")
+    ap.add_argument("--stack-cache", type=Path, default=None, metavar="DIR",
+                    help="Keep every decoded PNG slice as raw uint16 in a memory-mapped file under DIR (keyed by the file list, sizes and "
+                         "mtimes): a slice is decoded once, later epochs read it from the page cache")
+    ap.add_argument("--stack-cache-prefill", action="store_true", help="Decode the whole index into --stack-cache before the first step")
     ap.add_argument("--gpu-views", action="store_true",
                     help="Build both views on the GPU (HU decode, window, antialiased bicubic RandomResizedCrop, flip, normalise in one "
                          "kernel); DataLoader workers then only decode PNGs")
@@ -706,6 +712,17 @@ def main(argv=None) -> None:
             say(f"z_stride={args.z_stride} rows_before={len(rows)} rows_after={len(strided)}")
             rows = strided
         ds = PngDataset(rows, **ds_kw)
+        if args.stack_cache is not None:
+            from dinox.stackcache import SliceCache
+            t_c = time.time()
+            ds.cache = SliceCache([r.png_path for r in rows], args.stack_cache)
+            if args.stack_cache_prefill:
+                if main_rank:
+                    ds.cache.prefill(workers=hw.num_workers, say=say)
+                if world > 1:
+                    torch.distributed.barrier()
+            say(f"stack_cache={ds.cache.dir} slices={len(ds.cache)} cached={ds.cache.filled()} bytes={2 * ds.cache.total} "
+                f"setup_s={time.time() - t_c:.1f}")
     if len(ds) < args.batch_size:
         say(f"⚠️  Dataset size ({len(ds)}) is smaller than batch size ({args.batch_size}). Reducing batch size to {len(ds)}.")
         args.batch_size = cfg.batch_size = len(ds)
@@ -742,6 +759,9 @@ def main(argv=None) -> None:
     # (iter(dl) draws the loader's base seed from torch's global generator: both pipelines do it here, before the model is initialised,
     #  so that the same --train-seed gives the same initial weights with and without --gpu-views)
     it, prefetch = None, None
+    # --gpu-views writes the patch-embed operand itself (dinox_slice_views_patches): the fp32 image batch never exists.
+    # DINOX_VIEWS_IMAGE=1: the image batch + the separate unfold launch instead (A/B; bit-identical operand)
+    view_kw = {} if os.environ.get("DINOX_VIEWS_IMAGE") else dict(patch=model_cfg.patch, operand_dtype=torch.bfloat16 if args.amp else torch.float32)
     if args.gpu_views:
         from dinox.views import DevicePrefetcher
         prefetch = DevicePrefetcher(dl, device, ahead=not os.environ.get("DINOX_NO_PREFETCH"))     # the next batch crosses PCIe under this step
@@ -822,10 +842,10 @@ def main(argv=None) -> None:
                 _prof["ev"] = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 _prof["ev"][0].record()
             _t0 = time.perf_counter()
-            batch, spacing = make_views(sb, args.img_size, views=sb.views[:2]), sb.spacing
+            batch, spacing = make_views(sb, args.img_size, views=sb.views[:2], **view_kw), sb.spacing
             _prof["views"] += time.perf_counter() - _t0
             if args.local_crops:
-                loc = make_views(sb, args.local_size, views=sb.views[2:])
+                loc = make_views(sb, args.local_size, views=sb.views[2:], **view_kw)
                 spl = torch.cat([spacing] * args.local_crops, 0) if args.scale_aware else None
         else:
             try:

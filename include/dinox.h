@@ -252,6 +252,11 @@ int dinox_gram_normalize_bwd(const float* dxh, const void* shat, const float* sn
 int64_t dinox_slice_views_lds_bytes(int S, int max_crop);
 int dinox_slice_views(const void* raw_u16, const int64_t* view_i, const float* view_f, float* out, int V, int S, int max_crop,
                       void* stream);
+/* The same pipeline writing the patch-embed operand directly: u[(v P + gy g + gx)][c p^2 + py p + px] (row stride ld >= 3 p^2,
+ * g = S / patch, out_dtype DINOX_BF16 | DINOX_F32; columns 3 p^2 .. ld-1 are zeroed) -- bit for bit what dinox_patch_unfold(_ld)
+ * makes of dinox_slice_views' output, without writing and re-reading the fp32 image batch (4 + 4 B per pixel). */
+int dinox_slice_views_patches(const void* raw_u16, const int64_t* view_i, const float* view_f, void* u, int V, int S, int max_crop,
+                              int patch, int ld, int out_dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * KoLeo regulariser -- replaces KoLeoLoss.forward (scripts/phase5_big_run.py:742-773), which the loop applies

@@ -33,7 +33,8 @@ def test_flag_surface_matches_reference(cli):
     ap = cli.build_parser()
     have = {s for a in ap._actions for s in a.option_strings if s.startswith("--")} - {"--help"}
     assert set(REFERENCE_FLAGS) <= have
-    assert have - set(REFERENCE_FLAGS) == {"--synthetic", "--gpu-views", "--local-crops", "--local-size", "--hip-graph"}     # the documented extensions
+    assert have - set(REFERENCE_FLAGS) == {"--synthetic", "--gpu-views", "--local-crops", "--local-size", "--hip-graph", "--stack-cache",
+                                               "--stack-cache-prefill"}                                                  # the documented extensions
     d = vars(ap.parse_args([]))
     for k, v in REFERENCE_DEFAULTS.items():
         assert d[k] == v, k
@@ -90,6 +91,45 @@ def _write_pngs(tmp_path, n_series=3, n_slices=4, size=64):
         w.writeheader()
         w.writerows(rows)
     return csv_path
+
+
+def test_slice_cache_behind_png_dataset(cli, tmp_path):
+    """--stack-cache: every PNG is decoded once into a uint16 memmap keyed by (path, size, mtime); the dataset then returns the
+    same pixels as the decoder, a second process-lifetime (new SliceCache on the same directory) decodes nothing, a changed
+    file gets a fresh cache, and a parallel prefill fills every entry."""
+    import os
+    from dinox.stackcache import SliceCache, decode_png_u16, png_shape
+    from dinox.views import collate_stacks
+    rows = cli._load_index_rows(_write_pngs(tmp_path, n_series=2, n_slices=3, size=48), require_spacing=True)
+    root = tmp_path / "cache"
+    assert png_shape(rows[0].png_path) == (48, 48)
+    ds_plain = cli.PngDataset(rows, img_size=32)
+    ds = cli.PngDataset(rows, img_size=32)
+    ds.cache = SliceCache([r.png_path for r in rows], root)
+    assert len(ds.cache) == 6 and ds.cache.filled() == 0 and ds.cache.total == 6 * 48 * 48
+    for i in range(len(rows)):                                                   # first touch: decode + store
+        for a, b in zip(ds._stack(rows[i]), ds_plain._stack(rows[i])):
+            assert a.dtype == np.uint16 and np.array_equal(a, b)
+    assert ds.cache.filled() == 6 and ds.cache.misses == 6 and ds.cache.hits == 12     # 3 slices per stack, 6 distinct files
+    ds.raw_views = True                                                          # the --gpu-views item: memmap views straight into the batch buffer
+    sb = collate_stacks([ds[0], ds[4]])
+    back = sb.raw.numpy().view(np.uint16)
+    assert np.array_equal(back[:3 * 48 * 48].reshape(3, 48, 48), np.stack(ds_plain._stack(rows[0])))
+    again = SliceCache([r.png_path for r in rows], root)                         # a later run: everything is there
+    assert again.key == ds.cache.key and again.filled() == 6
+    assert np.array_equal(again.get(rows[3].png_path), decode_png_u16(rows[3].png_path)) and again.misses == 0
+    crc = again.checksum(again.index[str(rows[3].png_path)])
+    from PIL import Image                                                        # the file changes: new key, nothing stale
+    Image.fromarray(np.full((48, 48), 40000, dtype=np.uint16)).save(rows[3].png_path)
+    os.utime(rows[3].png_path, ns=(1, 1))
+    fresh = SliceCache([r.png_path for r in rows], root)
+    assert fresh.key != again.key and fresh.filled() == 0
+    assert fresh.prefill(workers=2) == 6 and fresh.filled() == 6 and fresh.prefill(workers=2) == 0
+    assert int(fresh.get(rows[3].png_path)[5, 7]) == 40000 and fresh.checksum(fresh.index[str(rows[3].png_path)]) != crc
+    with pytest.raises(KeyError):
+        fresh.get(tmp_path / "not_in_the_index.png")
+    with pytest.raises(FileNotFoundError):
+        SliceCache([rows[0].png_path], tmp_path / "other", create=False)
 
 
 def test_png_dataset_views_and_collate(cli, tmp_path):

@@ -98,6 +98,72 @@ def test_slice_views_vs_oracle(shapes, size, crop_scale):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shapes,size,patch,dt", [
+    ([(512, 512)] * 3, 224, 16, torch.bfloat16),               # BASELINE's layout: a 16 x 16 tile is one channel of one patch
+    ([(96, 120), (300, 280), (64, 64)], 224, 14, torch.bfloat16),      # patch 14 in bf16: 588 -> 640 columns, tail zeros; tiles straddle patches
+    ([(96, 120), (300, 280)], 224, 14, torch.float32),
+    ([(200, 333)], 96, 16, torch.float32),                     # the local-crop size of the multi-crop extension
+    ([(130, 70)], 32, 8, torch.bfloat16),
+])
+def test_slice_views_patches_is_unfold_of_slice_views(shapes, size, patch, dt):
+    """dinox_slice_views_patches (views written straight into the patch-embed operand) against the two-launch path it replaces:
+    bit for bit dinox_patch_unfold(_ld) of dinox_slice_views' image batch, and -- through an independent NumPy unfold of the oracle's
+    views -- within 1e-5 (fp32) / one bf16 rounding of the oracle."""
+    from dinox import ops
+    from dinox.views import make_views
+    items, sb = _batch(shapes, 2, size, seed=len(shapes) * 11 + size + patch, crop_scale=(0.3, 1.0))
+    sb = sb.to(DEV)
+    img = make_views(sb, size)
+    po = make_views(sb, size, patch=patch, operand_dtype=dt)
+    assert isinstance(po, ops.PatchOperand) and tuple(po.shape) == (2 * len(items), 3, size, size) and po.u.dtype == dt
+    want = ops.patch_unfold(img, patch, dt)
+    assert po.u.shape == want.shape and torch.equal(po.u.view(torch.int16 if dt == torch.bfloat16 else torch.int32),
+                                                    want.view(torch.int16 if dt == torch.bfloat16 else torch.int32))
+    assert ops.patch_unfold(po, patch, dt) is po.u                                 # the model takes it as its operand, no copy
+    with pytest.raises(ValueError, match="unfolded for patch"):
+        ops.patch_unfold(po, patch * 2, dt)
+    g, B, K0 = size // patch, len(items), 3 * patch * patch
+    got = po.u.float().cpu().numpy()
+    assert not got[:, K0:].any()                                                   # padded columns
+    for k in range(2):
+        for i, (stack, views, _) in enumerate(items):
+            v = views[k]
+            ref = S.make_view(stack, v.level, v.width, v.top, v.left, v.h, v.w, v.flip, size)           # (3, size, size)
+            rows = ref.reshape(3, g, patch, g, patch).transpose(1, 3, 0, 2, 4).reshape(g * g, K0)       # [gy gx][c py px]
+            mine = got[(k * B + i) * g * g:(k * B + i + 1) * g * g, :K0]
+            tol = 1e-5 if dt == torch.float32 else 2.0 ** -8 * np.maximum(np.abs(rows), 1e-3) + 1e-5
+            assert np.all(np.abs(mine - rows) <= tol), f"view {k} sample {i}"
+
+
+@pytest.mark.gpu
+def test_patch_operand_batch_trains_like_the_image_batch():
+    """One engine step fed with the fused operand equals the step fed with the image batch of the same draws: the operand is
+    bit-identical, so loss and updated weights must be too (bf16 mode, BASELINE's patch 16; captured-step clone/copy included)."""
+    import copy
+    from dinox import ops
+    from dinox.engine import StepHyperParams, TrainEngine
+    from dinox.views import make_views
+    from zoo.arch import DinoStudentTeacher, PatchViT
+    items, sb = _batch([(80, 80)] * 4, 2, 32, seed=3)
+    sb = sb.to(DEV)
+    torch.manual_seed(0)
+    kw = dict(img_size=32, patch=16, dim=64, depth=2, heads=2, scale_aware=True)
+    s0 = DinoStudentTeacher(PatchViT(**kw), out_dim=256).to(DEV)
+    res = []
+    for fused in (False, True):
+        st, te = copy.deepcopy(s0), copy.deepcopy(s0)
+        eng = TrainEngine(st, te, 256, StepHyperParams(lr=1e-3, warmup_steps=1, max_steps=4), amp_dtype=torch.bfloat16)
+        batch = make_views(sb, 32, patch=16, operand_dtype=torch.bfloat16) if fused else make_views(sb, 32)
+        sp = torch.cat([sb.spacing, sb.spacing], 0).to(DEV)
+        out = eng.step(batch, sp)
+        res.append((float(out["loss"]), eng.flat_p.clone()))
+    assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1])
+    po = make_views(sb, 32, patch=16, operand_dtype=torch.bfloat16)
+    c = po.clone()
+    assert c.u.data_ptr() != po.u.data_ptr() and torch.equal(c.u, po.u) and c.copy_(po) is c and c.device == po.u.device
+
+
+@pytest.mark.gpu
 def test_slice_views_full_batch_properties():
     """BASELINE's batch (256 stacks of 512x512 -> 512 views of 224x224) through size-independent properties: a constant stack
     maps to the constant (window(c) - mean) / std whatever the crop (weights sum to 1); flipping is an exact mirror; the

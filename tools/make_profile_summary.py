@@ -35,6 +35,10 @@ total_ns = sum(float(r["TotalDurationNs"]) for r in rows)
 prof_line = json.loads(json_line(os.path.join(src, "bench_prof.log")))
 default_line = json_line(os.path.join(src, "bench_default.log"))
 steps = prof_line["steps"] + prof_line["warmup"]
+# every optimiser step of the process launches adamw_ema_kernel once -- the timed + warm-up steps AND the few extra ones bench.py runs on an
+# empty queue for host_enqueue_ms_per_step: count what the trace holds
+opt_calls = sum(int(r["Calls"]) for r in rows if "adamw_ema" in r["Name"])
+steps = opt_calls or steps
 fam = {}
 for r in rows:
     f = r["Name"].replace("void ", "").split("(")[0].split("<")[0]
@@ -45,7 +49,7 @@ dom = prof_line["roofline"]["kernel"]
 dom_key = next(k for k in fam if k.endswith(dom))
 md = [f"# rocprofv3 --kernel-trace --stats summary, round {tag[1:]}", "",
       "Command (MI355X, 1 GPU): `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-step-split`",
-      f"({steps} optimiser steps of ViT-S/16 224 bs256 = 512 views, bf16 mode, everything on one stream; HIP-event kernel timing active as in the "
+      f"({steps} optimiser steps in the trace ({prof_line['warmup']} warm-up + {prof_line['steps']} timed + the empty-queue host-enqueue steps) of ViT-S/16 224 bs256 = 512 views, bf16 mode, everything on one stream; HIP-event kernel timing active as in the "
       f"default bench run).  Raw CSV: `{tag}_bench_bs256_kernel_stats.csv`.  Regenerate: `tools/refresh_profiles.sh` on the GPU box, then "
       "`tools/make_profile_summary.py`.", "",
       "| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]

@@ -201,7 +201,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_big(GemmParams p, int til
 
 #undef TB_STAGE
 
-// Which big-tile form (0: none, 1: 256 x 192, 2: 384 x 128) and its split plan.  Needs the deterministic-reduction envelope
+// Which big-tile form (0: none, 1: 256 x 192, 2: 384 x 128, 3: 256 x 256) and its split plan.  Needs the deterministic-reduction envelope
 // (one contiguous fp32 [M][N] result, plain epilogue) and enough K to fill a four-deep ring on every workgroup.
 int tn_big_plan(const GemmParams& p, int& tiles_m, int& tiles_n, int& splits, int64_t& kps) {
   if (p.transA != 1 || p.transB != 1 || p.batch != 1 || p.ldc != p.N || p.out_dtype != DINOX_F32 || p.in_dtype != DINOX_BF16) return 0;
@@ -212,19 +212,31 @@ int tn_big_plan(const GemmParams& p, int& tiles_m, int& tiles_n, int& splits, in
   if (p.K < 8192) return 0;
   static const bool off = getenv("DINOX_TN_BIG_OFF") != nullptr;
   if (off) return 0;
-  // staged bytes per k-row ~ tiles x (TM + TN): take the cheaper of the two shapes
-  const int64_t c1 = ceil_div(p.M, (int64_t)256) * ceil_div(p.N, (int64_t)192) * (256 + 192);
-  const int64_t c2 = ceil_div(p.M, (int64_t)384) * ceil_div(p.N, (int64_t)128) * (384 + 128);
-  const int form = c1 <= c2 ? 1 : 2;
-  tiles_m = (int)ceil_div(p.M, (int64_t)(form == 1 ? 256 : 384));
-  tiles_n = (int)ceil_div(p.N, (int64_t)(form == 1 ? 192 : 128));
-  const int64_t ntile = (int64_t)tiles_m * tiles_n;
-  if (ntile > 256) return 0;
-  splits = (int)(256 / ntile);                                  // one resident round: one workgroup per CU
-  const int64_t max_splits = ceil_div(p.K, (int64_t)(8 * TB_BK));
-  if (splits > max_splits) splits = (int)max_splits;
-  if (splits < 1) splits = 1;
-  kps = ceil_div(ceil_div(p.K, (int64_t)splits), (int64_t)TB_BK) * TB_BK;
+  // Three tile shapes (1: 256 x 192, 2: 384 x 128, 3: 256 x 256); every workgroup of the ONE resident round does kps k-rows of a whole
+  // tile (padding included), so the product's time goes with  kps x TM x TN  of the shape's own split plan -- ViT-L's 4096 x 1024
+  // dW1 is 96 tiles of 256 x 192 (two splits: 192 of 256 CUs busy, 11 % of the tile area padding) but 64 tiles of 256 x 256 (four
+  // splits, every CU, no padding).  Ties go to the shape that stages fewer bytes per k-row (TM + TN).  DINOX_TN_FORM=1|2|3 forces one (A/B).
+  const char* fenv = getenv("DINOX_TN_FORM");                 // (read per call: tools flip it between launches)
+  const int forced = fenv ? atoi(fenv) : 0;
+  static const int TMs[4] = {0, 256, 384, 256}, TNs[4] = {0, 192, 128, 256};
+  int form = 0;
+  int64_t best = 0;
+  for (int f = 1; f <= 3; ++f) {
+    if (forced >= 1 && forced <= 3 && f != forced) continue;
+    const int tm_ = (int)ceil_div(p.M, (int64_t)TMs[f]), tn_ = (int)ceil_div(p.N, (int64_t)TNs[f]);
+    const int64_t nt = (int64_t)tm_ * tn_;
+    if (nt > 256) continue;
+    int sp = (int)(256 / nt);                                   // one resident round: one workgroup per CU
+    const int64_t max_splits = ceil_div(p.K, (int64_t)(8 * TB_BK));
+    if (sp > max_splits) sp = (int)max_splits;
+    if (sp < 1) sp = 1;
+    const int64_t kp = ceil_div(ceil_div(p.K, (int64_t)sp), (int64_t)TB_BK) * TB_BK;
+    const int64_t cost = kp * TMs[f] * TNs[f];
+    if (form == 0 || cost < best || (cost == best && TMs[f] + TNs[f] < TMs[form] + TNs[form])) {
+      form = f; best = cost; tiles_m = tm_; tiles_n = tn_; kps = kp;
+    }
+  }
+  if (!form) return 0;
   splits = (int)ceil_div(p.K, kps);
   return form;
 }
@@ -249,10 +261,14 @@ int launch_gemm_bf16_tn_big(const GemmParams& p, hipStream_t st, int& splits_out
     constexpr size_t lds = (size_t)TB_STAGES * 7 * TB_SUB;
     if (int rc = reserve_lds(reinterpret_cast<const void*>(gemm_bf16_tn_big<2, 3>), lds, "gemm_bf16_tn_big")) return rc;
     hipLaunchKernelGGL((gemm_bf16_tn_big<2, 3>), dim3(grid), dim3(512), lds, st, p, tiles_m, tiles_n, splits, kps);
-  } else {
+  } else if (form == 2) {
     constexpr size_t lds = (size_t)TB_STAGES * 8 * TB_SUB;
     if (int rc = reserve_lds(reinterpret_cast<const void*>(gemm_bf16_tn_big<3, 2>), lds, "gemm_bf16_tn_big")) return rc;
     hipLaunchKernelGGL((gemm_bf16_tn_big<3, 2>), dim3(grid), dim3(512), lds, st, p, tiles_m, tiles_n, splits, kps);
+  } else {
+    constexpr size_t lds = (size_t)TB_STAGES * 8 * TB_SUB;
+    if (int rc = reserve_lds(reinterpret_cast<const void*>(gemm_bf16_tn_big<2, 4>), lds, "gemm_bf16_tn_big")) return rc;
+    hipLaunchKernelGGL((gemm_bf16_tn_big<2, 4>), dim3(grid), dim3(512), lds, st, p, tiles_m, tiles_n, splits, kps);
   }
   return check_launch("gemm_bf16_tn_big");
 }

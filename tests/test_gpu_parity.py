@@ -1641,7 +1641,8 @@ def test_graph_replay_matches_eager(dx):
 
 
 @pytest.mark.parametrize("K,M,N,cs", [(102912, 1536, 384, True), (25728, 384, 384, True), (5000, 1152, 384, False), (804 * 32 + 17, 136, 264, True),
-                                      (102912, 384, 1536, True), (30000, 1152, 384, True), (100352, 384, 768, False), (9000, 64, 72, True)])
+                                      (102912, 384, 1536, True), (30000, 1152, 384, True), (100352, 384, 768, False), (9000, 64, 72, True),
+                                      (12864, 4096, 1024, True), (12864, 1024, 1024, True), (9000, 3072, 1024, True)])      # ViT-L: the 256 x 256 / 384 x 128 forms
 def test_gemm_tn_split_k_is_bit_reproducible(dx, K, M, N, cs):
     """The dW products (C[M,N] = A[K,M]^T B[K,N], K = every token of the batch) split K over the chip.  With the workspace the host
     side hands them (ops._tn_workspace) the splits meet in a fixed-order two-stage reduction instead of fp32 atomics: five launches
@@ -1671,6 +1672,30 @@ def test_gemm_tn_split_k_is_bit_reproducible(dx, K, M, N, cs):
     assert rel_l2(outs[0][0] - C0, ref) < 1e-5
     if cs:
         assert rel_l2(outs[0][1] - c0, A.double().sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("form", ["1", "2", "3"])
+def test_gemm_tn_big_every_tile_form(dx, form, monkeypatch):
+    """gemm_bf16_tn_big has three tile shapes (256 x 192, 384 x 128, 256 x 256; the plan picks by kps x TM x TN): each one forced
+    (DINOX_TN_FORM) on a ragged product -- partial tiles in both directions, a K that is no multiple of the 32-row step -- against fp64,
+    with the bias gradient, twice for bit-reproducibility."""
+    ops, _ = dx
+    monkeypatch.setenv("DINOX_TN_FORM", form)
+    K, M, N = 9000 + 24, 1096, 520
+    g = torch.Generator().manual_seed(int(form))
+    A = (torch.randn(K, M, generator=g) * 0.5).bfloat16().to(DEV)
+    B = (torch.randn(K, N, generator=g) * 0.5).bfloat16().to(DEV)
+    outs = []
+    ops.TRACE_KERNELS = []
+    try:
+        for _ in range(2):
+            cvec = torch.zeros(M, device=DEV)
+            outs.append((ops.gemm(A, B, transA=True, transB=True, out_dtype=torch.float32, colsum_out=cvec), cvec))
+        assert set(ops.TRACE_KERNELS) == {"gemm_bf16_tn_big"}
+    finally:
+        ops.TRACE_KERNELS = None
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert rel_l2(outs[0][0], A.double().t() @ B.double()) < 2e-6 and rel_l2(outs[0][1], A.double().sum(0)) < 1e-5
 
 
 def test_training_steps_are_bit_reproducible(dx):

@@ -885,6 +885,236 @@ __global__ __launch_bounds__(448) void attn_bwd_fused_bf16(const bf16_t* __restr
   }
 }
 
+// ------------------------------------------------------------------------------------------ qkv projection + attention, one kernel
+// north_star's "fused QKV projection + multi-head attention" as ONE launch: for the passes that keep nothing for a backward (the teacher
+// of a training step, encode()) the packed qkv tensor -- 237 MB per layer at the hot-path shape, written by one launch and read straight
+// back by the next -- never exists.  One workgroup per CU walks (image, head) pairs, one wave per 32 tokens (193..224 tokens):
+//   projection   [q | k | v](32 tokens x 192) of the wave's tokens = LN(x)[32 x D] . W_h^T + b_h, as six 32 x 32 accumulator blocks computed
+//                TRANSPOSED (weights as the A operand: a lane holds four consecutive features of ONE token, 8 bytes of an image row);
+//                K-steps of 32: the head's weight slice [192][32] (12 KiB, shared) and the wave's own token rows [32][32] (2 KiB) arrive
+//                by LDS-DMA in a two-slot ring, one barrier per step;
+//   hand-over    q -> the wave's 32-row image in its staging tile, k / v -> rows 32 w .. of the K / V images, in the layout the
+//                attention kernels read (img_off); optionally the packed qkv rows leave for HBM too (qkv_out != null);
+//   attention    exactly attn_fwd_bf16_persist's one-pass block (S^T strip in registers, lane-local softmax, P as the next A operand).
+// The pairs of one image are kept on one XCD (its six heads run side by side: the token rows come out of that XCD's L2, the weights
+// -- 0.9 MB for all heads -- stay there).
+// MEASURED (tools/qkv_attn_bench.py): correct, and NOT faster than the two launches it replaces -- 219-227 us against
+// 208-222 us at (512, 201, 6, 384), 500 against 408 us at ViT-L's (256, 201, 16, 1024).  The projection of a pair streams
+// D x (192 + 224) x 2 B through L2 -> LDS with a 224 x 192 tile's reuse (the stand-alone product runs 256 x 256 tiles in a ping-pong
+// schedule), every pair starts its ring cold (~3 us: s_memtime stamps) and the hand-over costs ~2 us; a four-stage ring with the token
+// rows prefetched into registers three steps ahead was built and measured no faster (227 us): the steps are bound by the ~2.5 us
+// issue-to-landed latency of the staging loads divided by the ring depth.  The kernel therefore stays OPT-IN (DINOX_QKV_FUSED=1).
+constexpr int QA_WSLOT = 192 * 64, QA_XSLOT = 32 * 64;          // [192 features][32 k], [32 tokens][32 k] bf16 (64-byte rows)
+
+template <int NKT>
+__global__ __launch_bounds__(NKT * 64) void attn_qkv_fused_fwd(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                              const float* __restrict__ bias, bf16_t* __restrict__ o,
+                                                              bf16_t* __restrict__ qkv_out, float* __restrict__ lse, int B, int N, int heads,
+                                                              int D, float sc) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int npad = NKT * 32, img_bytes = npad * 128;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int C = heads * AT_D, hl = lane >> 5;
+  char* const kimg = smem;
+  char* const vimg = smem + img_bytes;
+  char* const wring = smem + 2 * img_bytes;
+  char* const xring = wring + 2 * QA_WSLOT + wv * 2 * QA_XSLOT;
+  char* const st_scratch = wring + 2 * QA_WSLOT + NKT * 2 * QA_XSLOT + wv * ST_BYTES;
+  float* const inv_s = reinterpret_cast<float*>(wring + 2 * QA_WSLOT + NKT * 2 * QA_XSLOT + NKT * ST_BYTES) + wv * 32;
+  float* const bias_s = reinterpret_cast<float*>(wring + 2 * QA_WSLOT + NKT * 2 * QA_XSLOT + NKT * ST_BYTES) + NKT * 32;
+  const int nk = D / 32;
+
+  // pairs of this workgroup: image b lives on XCD b % 8 (consecutive workgroup ids go round the XCDs), its heads on neighbouring CUs;
+  // a handful of images (encode() of one slice) are dealt out pair by pair instead
+  const int nx = B >= 64 ? 8 : 1;
+  const int xcd = nx == 8 ? (int)(blockIdx.x & 7) : 0, widx = nx == 8 ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int nwx = nx == 8 ? (int)((gridDim.x + 7 - xcd) >> 3) : (int)gridDim.x;                      // workgroups that share this list
+  const int nimg = nx == 8 ? (B > xcd ? (B - xcd + 7) >> 3 : 0) : B;                                 // images on the list
+  const int npx = nimg * heads;
+
+  // staging addresses: instruction i of a slab covers rows 16 i .. 16 i + 15 (64 B each), chunk c of row r from source chunk c ^ ((r >> 2) & 3)
+  const int srow = lane >> 2, schunk = lane & 3;
+  unsigned xoff[2];
+  int64_t woff[2];
+  bool wmine[2];
+  f32x16 pend[2];
+  float pend_lse = 0.f;
+  int pend_b = -1, pend_h = 0;                          // wave-uniform
+  auto store_pending = [&]() {
+    if (lse != nullptr && hl == 0 && wv * 32 + lane < N) lse[((int64_t)pend_b * heads + pend_h) * N + wv * 32 + lane] = pend_lse;
+    store_block(o + (int64_t)pend_b * N * C + pend_h * AT_D, C, wv * 32, N, pend[0], pend[1], st_scratch, lane);
+  };
+
+  for (int j = widx; j < npx; j += nwx) {
+    const int b = nx * (j / heads) + xcd, hh = j % heads;
+    const bf16_t* const xb = x + (int64_t)b * N * D;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int r = 16 * q + srow;                        // token row of the wave's block
+      int tok = wv * 32 + r;
+      tok = tok < N ? tok : N - 1;                        // rows past N repeat the last token (finite; masked as keys, never stored as queries)
+      xoff[q] = (unsigned)((tok * D + (schunk ^ ((r >> 2) & 3)) * 8) * 2);
+      const int i = wv + NKT * q, f = 16 * i + srow;      // weight slab instruction i (12 of them), feature f of [q | k | v] of this head
+      wmine[q] = i < 12;
+      const int fc = f < 192 ? f : 0;
+      woff[q] = ((int64_t)((fc >> 6) * C + hh * AT_D + (fc & 63)) * D + (schunk ^ ((fc >> 2) & 3)) * 8) * 2;
+    }
+    auto stage = [&](int slot, int kt) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        if (wmine[q])
+          __builtin_amdgcn_global_load_lds((at_gbl_void*)((const char*)w + woff[q] + kt * 64), (at_lds_void*)(wring + slot * QA_WSLOT + (wv + NKT * q) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((at_gbl_void*)((const char*)xb + xoff[q] + kt * 64), (at_lds_void*)(xring + slot * QA_XSLOT + q * 1024), 16, 0, 0);
+      }
+    };
+    if (threadIdx.x < 192) {
+      const int f = threadIdx.x;
+      bias_s[f] = bias ? bias[(f >> 6) * C + hh * AT_D + (f & 63)] : 0.f;     // (read after the K loop's barriers)
+    }
+    f32x16 acc[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) zero16(acc[i]);
+    stage(0, 0);
+    const int frow = lane & 31;
+    for (int kt = 0; kt < nk; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+      if (kt == 1 && pend_b >= 0) store_pending();        // the previous pair's output, one pair late (its stores drain under the K loop)
+      const char* ws = wring + (kt & 1) * QA_WSLOT;
+      const char* xs = xring + (kt & 1) * QA_XSLOT;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int kc = 2 * ks + hl;
+        const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xs + frow * 64 + ((kc ^ ((frow >> 2) & 3)) << 4));
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          const int rw = i * 32 + frow;
+          const bf16x8 wf = *reinterpret_cast<const bf16x8*>(ws + rw * 64 + ((kc ^ ((rw >> 2) & 3)) << 4));
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[i], 0, 0, 0);       // [features][tokens]
+        }
+      }
+    }
+    if (nk < 2 && pend_b >= 0) store_pending();
+    // ---- hand-over: acc[i][4 g + r] = feature 32 (i & 1) + 8 g + 4 hl + r of section i >> 1, token frow of the wave's block
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      char* const img = i < 2 ? st_scratch : (i < 4 ? kimg : vimg);
+      const int row = i < 2 ? frow : wv * 32 + frow;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 b4 = *reinterpret_cast<const float4*>(bias_s + (i >> 1) * 64 + (i & 1) * 32 + 8 * g + 4 * hl);
+        uint2 pk;
+        pk.x = (unsigned)f32_to_bf16(acc[i][4 * g] + b4.x) | ((unsigned)f32_to_bf16(acc[i][4 * g + 1] + b4.y) << 16);
+        pk.y = (unsigned)f32_to_bf16(acc[i][4 * g + 2] + b4.z) | ((unsigned)f32_to_bf16(acc[i][4 * g + 3] + b4.w) << 16);
+        *reinterpret_cast<uint2*>(img + img_off(row, 4 * (i & 1) + g) + 8 * hl) = pk;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                         // every wave's k, v rows are in the images
+    __builtin_amdgcn_sched_barrier(0);
+    if (qkv_out != nullptr) {                             // the packed rows, for a caller that keeps them (whole 128-byte row pieces)
+#pragma unroll
+      for (int sec = 0; sec < 3; ++sec) {
+        const char* img = sec == 0 ? st_scratch : (sec == 1 ? kimg : vimg);
+        const int rbase = sec == 0 ? 0 : wv * 32;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int r = (lane >> 3) + 8 * t, c = lane & 7, tok = wv * 32 + r;
+          const uint4 v = *reinterpret_cast<const uint4*>(img + img_off(rbase + r, c));
+          if (tok < N) *reinterpret_cast<uint4*>(qkv_out + ((int64_t)b * N + tok) * 3 * C + sec * C + hh * AT_D + c * 8) = v;
+        }
+      }
+    }
+    // ---- attention of the wave's 32 queries (attn_fwd_bf16_persist, one pass)
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(st_scratch + img_off(frow, 2 * ks + hl));
+    const char* kr[4];
+    const char* vt[2][2][2];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) kr[ks] = kimg + img_off(frow, 2 * ks + hl);
+    {
+      const int i = lane & 15, g = lane >> 4, q4 = i >> 2, pp = i & 3;
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const int ch = (dt * 32 >> 3) + 2 * (g & 1) + (pp >> 1);
+          const int r0 = 16 * ss + 4 * (g >> 1) + q4;
+          vt[ss][dt][0] = vimg + img_off(r0, ch) + 8 * (pp & 1);
+          vt[ss][dt][1] = vimg + img_off(r0 + 8, ch) + 8 * (pp & 1);
+        }
+    }
+    const float c2 = sc * 1.4426950408889634f;
+    f32x16 oacc[2];
+    zero16(oacc[0]);
+    zero16(oacc[1]);
+    float sum = 0.f, mx = -INFINITY;
+    {
+      f32x16 st[NKT];
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) {
+        zero16(st[kt]);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+          st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(kr[ks] + kt * 4096), qf[ks], st[kt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          if (kt == NKT - 1 && !(kt * 32 + acc_row(e, hl) < N)) st[kt][e] = -INFINITY;
+          mx = fmaxf(mx, st[kt][e]);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mx2 = mx * c2;
+      mx *= sc;
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float pr = __builtin_amdgcn_exp2f(st[kt][e] * c2 - mx2);
+          st[kt][e] = pr;
+          sum += pr;
+        }
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+          const bf16x8 pa = acc_as_a(st[kt], ss);
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt)
+            oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, rd_tr_pair(vt[ss][dt][0] + kt * 4096, vt[ss][dt][1] + kt * 4096), oacc[dt], 0, 0, 0);
+        }
+      }
+    }
+    sum += __shfl_xor(sum, 32, 64);
+    if (hl == 0) inv_s[lane] = 1.0f / sum;
+    pend_lse = mx + __logf(sum);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 iv = *reinterpret_cast<const float4*>(inv_s + 8 * g + 4 * hl);
+      const float ivv[4] = {iv.x, iv.y, iv.z, iv.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        oacc[0][4 * g + r] *= ivv[r];
+        oacc[1][4 * g + r] *= ivv[r];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    pend[0] = oacc[0];
+    pend[1] = oacc[1];
+    pend_b = b;
+    pend_h = hh;
+  }
+  if (pend_b >= 0) store_pending();
+}
+
 // ------------------------------------------------------------------------------------------ launchers
 // Workgroups of a persistent attention kernel that fit one CU: 160 KiB of LDS, and 8 waves (the kernels sit at ~250 registers: two per SIMD).
 static int persist_wgs_per_cu(size_t lds_bytes, int waves) {
@@ -939,6 +1169,24 @@ int launch_attention_bf16_fwd(const void* qkv, void* o, float* lse, int B, int N
   if (nblk <= 2) FWD(2); else if (nblk <= 4) FWD(4); else if (nblk <= 7) FWD(7); else FWD(9);
 #undef FWD
   return check_launch("attention_bf16_fwd");
+}
+
+// x [B N][D] bf16 (LayerNorm output), w [3 C][D] bf16 (C = heads * 64), bias [3 C] fp32 or null -> o [B N][C] bf16 (+ qkv_out [B N][3 C], lse)
+bool attention_qkv_fused_ok(int B, int N, int heads, int d, int D) {
+  return d == AT_D && N > 192 && N <= 224 && D >= 32 && D % 32 == 0 && B > 0 && heads > 0 && (int64_t)N * D * 2 < ((int64_t)1 << 31);
+}
+int launch_attention_qkv_fused_fwd(const void* x, const void* w, const float* bias, void* o, void* qkv_out, float* lse, int B, int N, int heads,
+                                   int d, int D, hipStream_t st) {
+  if (!attention_qkv_fused_ok(B, N, heads, d, D)) return DINOX_EUNSUPPORTED;
+  if ((((uintptr_t)x | (uintptr_t)w | (uintptr_t)o | (uintptr_t)qkv_out | (uintptr_t)bias) & 15) != 0) return DINOX_EALIGN;
+  constexpr int NKT = 7;
+  const size_t lds = (size_t)2 * NKT * 32 * 128 + 2 * QA_WSLOT + (size_t)NKT * 2 * QA_XSLOT + (size_t)NKT * ST_BYTES + NKT * 32 * sizeof(float) + 192 * sizeof(float);
+  if (int rc = allow_lds(attn_qkv_fused_fwd<NKT>, lds)) return fail(rc, "qkv_attention_fwd: cannot reserve %zu B of LDS", lds);
+  const int64_t npairs = (int64_t)B * heads;
+  const int nwg = npairs < 256 ? (int)npairs : 256;
+  hipLaunchKernelGGL((attn_qkv_fused_fwd<NKT>), dim3(nwg), dim3(NKT * 64), lds, st, (const bf16_t*)x, (const bf16_t*)w, bias, (bf16_t*)o,
+                     (bf16_t*)qkv_out, lse, B, N, heads, D, 1.0f / sqrtf((float)d));
+  return check_launch("qkv_attention_fwd");
 }
 
 int launch_attention_bf16_bwd(const void* d_o, const void* qkv, const void* o, const float* lse, void* dqkv, float* ws, int B,

@@ -67,7 +67,10 @@ extern "C" int dinox_block_forward(const dinox_block_fwd_args* a, void* stream) 
   DX_REQUIRE(a, DINOX_EINVAL, "block_forward: null args");
   DX_REQUIRE(a->V > 0 && a->N > 0 && a->D > 0 && a->H > 0 && a->heads > 0 && a->D % a->heads == 0, DINOX_EINVAL,
              "block_forward: V=%lld N=%lld D=%d H=%d heads=%d", (long long)a->V, (long long)a->N, a->D, a->H, a->heads);
-  DX_REQUIRE(a->x0 && a->qkv && a->o && a->lse && a->x1 && a->xn2 && a->mean2 && a->rstd2 && a->act && a->x2, DINOX_EINVAL, "block_forward: null activation");
+  DX_REQUIRE(a->x0 && a->o && a->x1 && a->xn2 && a->mean2 && a->rstd2 && a->act && a->x2, DINOX_EINVAL, "block_forward: null activation");
+  // qkv == NULL (a pass that keeps nothing for a backward): the qkv projection and the attention run as ONE launch and the packed qkv
+  // tensor never exists (dinox_qkv_attention_fwd; the caller has asked dinox_qkv_attention_ok)
+  DX_REQUIRE(a->qkv ? a->lse != nullptr : !a->train, DINOX_EINVAL, "block_forward: qkv / lse buffers (only a no-grad pass may leave qkv out)");
   DX_REQUIRE(a->n1w && a->n1b && a->n2w && a->n2b && a->wqkv && a->wproj && a->w1 && a->w2, DINOX_EINVAL, "block_forward: null parameter");
   DX_REQUIRE(a->xn1_in ? (a->mean1_in && a->rstd1_in) : (a->xn1 && a->mean1 && a->rstd1), DINOX_EINVAL, "block_forward: norm1 buffers");
   DX_REQUIRE(!a->next_g || (a->next_b && a->yn && a->meann && a->rstdn), DINOX_EINVAL, "block_forward: next LayerNorm buffers");
@@ -80,13 +83,15 @@ extern "C" int dinox_block_forward(const dinox_block_fwd_args* a, void* stream) 
     BLK_TRY(dinox_layernorm_fwd(a->x0, a->n1w, a->n1b, a->xn1, a->mean1, a->rstd1, M, D, a->eps, DINOX_BF16, stream));
     xn1 = a->xn1;
   }
-  // qkv = xn1 Wqkv^T + b
-  {
+  if (!a->qkv) {
+    BLK_TRY(dinox_qkv_attention_fwd(xn1, a->wqkv, a->bqkv, a->o, nullptr, a->lse, (int)a->V, (int)a->N, a->heads, D / a->heads, D, stream));
+  } else {
+    // qkv = xn1 Wqkv^T + b
     dinox_gemm_args g = gemm_args(xn1, a->wqkv, a->qkv, M, 3 * (int64_t)D, D, DINOX_BF16);
     if (a->bqkv) { g.epilogue |= DINOX_EPI_BIAS; g.bias = a->bqkv; }
     BLK_TRY(dinox_gemm(&g, stream));
+    BLK_TRY(dinox_attention_fwd(a->qkv, a->o, a->lse, (int)a->V, (int)a->N, a->heads, D / a->heads, DINOX_BF16, stream));
   }
-  BLK_TRY(dinox_attention_fwd(a->qkv, a->o, a->lse, (int)a->V, (int)a->N, a->heads, D / a->heads, DINOX_BF16, stream));
   // x1 = x0 + o Wproj^T + b ; xn2 = norm2(x1)
   if (a->fuse_proj_ln) {
     BLK_TRY(dinox_linear_residual_ln(a->o, a->wproj, a->bproj, a->x0, a->x1, a->n2w, a->n2b, a->eps, a->xn2, DINOX_BF16, a->mean2, a->rstd2, M, D, D, stream));

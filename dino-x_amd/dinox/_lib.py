@@ -79,6 +79,8 @@ SIGNATURES = {
     "dinox_attention_fwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "dinox_attention_bwd_ws_bytes": (i64, [i32, i32, i32]),
     "dinox_attention_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "dinox_qkv_attention_ok": (i32, [i32, i32, i32, i32, i32]),
+    "dinox_qkv_attention_fwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "dinox_patch_unfold": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "dinox_patch_unfold_ld": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "dinox_tokens_fwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),

@@ -626,6 +626,35 @@ def attention_fwd(qkv: Tensor, heads: int):
     return o, lse
 
 
+# "1": no-grad blocks (teacher, encode()) run qkv projection + attention as one launch.  Off by default: measured no faster than the two
+# launches at ViT-S (219-227 us against 208-222) and slower at ViT-L (500 against 408 us); csrc/attention_bf16.hip, DESIGN.md section 4
+_QKV_FUSED = os.environ.get("DINOX_QKV_FUSED", "0") == "1"
+
+
+def qkv_attention_ok(B: int, N: int, heads: int, D: int, C: int) -> bool:
+    """Is (B images of N tokens, width D in, heads x 64 out) inside the fused qkv-projection + attention kernel?"""
+    return C % heads == 0 and bool(lib.dinox_qkv_attention_ok(B, N, heads, C // heads, D))
+
+
+def qkv_attention(x: Tensor, w: Tensor, bias: Optional[Tensor], heads: int, want_qkv: bool = False, want_lse: bool = False):
+    """o = attention(x w^T + bias) in ONE launch (dinox_qkv_attention_fwd): x [B,N,D] bf16, w [3C,D] bf16, bias [3C] fp32 or None
+    -> o [B,N,C] bf16; with want_qkv / want_lse also the packed qkv rows [B,N,3C] / the log-sum-exp [B,heads,N] (else None).
+    Replaces Attention.qkv + the attention core (zoo/arch.py:46-52) for passes that keep nothing for a backward."""
+    _need_cuda(x, w)
+    x, w = _c(x), _c(w)
+    B, N, D = x.shape
+    C = w.shape[0] // 3
+    assert x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and w.shape == (3 * C, D) and C % heads == 0
+    o = torch.empty((B, N, C), dtype=torch.bfloat16, device=x.device)
+    qkv = torch.empty((B, N, 3 * C), dtype=torch.bfloat16, device=x.device) if want_qkv else None
+    lse = torch.empty((B, heads, N), dtype=torch.float32, device=x.device) if want_lse else None
+    if TRACE_KERNELS is not None:
+        TRACE_KERNELS.append("attn_qkv_fused_fwd")
+    check(lib.dinox_qkv_attention_fwd(_p(x), _p(w), _p(None if bias is None else _c(bias)), _p(o), _p(qkv), _p(lse), B, N, heads, C // heads, D,
+                                      _stream()), "dinox_qkv_attention_fwd")
+    return o, qkv, lse
+
+
 def attention_bwd(do: Tensor, qkv: Tensor, o: Tensor, lse: Tensor, heads: int) -> Tensor:
     do = to_mode(do, qkv.dtype)
     B, N, C3 = qkv.shape
@@ -889,7 +918,10 @@ def _block_forward_native(ctx, x0, n1w, n1b, wqkv, bqkv, wproj, bproj, n2w, n2b,
         xn1, mean1, rstd1 = bf(V, N, D), f32(M), f32(M)
     else:
         xn1, mean1, rstd1 = pre_ln
-    qkv, o, lse = bf(M, 3 * D), bf(V, N, D), f32(V, heads, N)
+    if not train and _QKV_FUSED and qkv_attention_ok(V, N, heads, D, D):      # no backward: projection + attention in one launch, no qkv tensor
+        qkv, o, lse = None, bf(V, N, D), None
+    else:
+        qkv, o, lse = bf(M, 3 * D), bf(V, N, D), f32(V, heads, N)
     x1, xn2, mean2, rstd2 = f32(M, D), bf(M, D), f32(M), f32(M)
     act = bf(M, H)
     pre = bf(M, H) if train else None
@@ -986,6 +1018,20 @@ def _block_backward_native(ctx, g: Tensor, saved):
     return (g1,) + (None,) * 16
 
 
+_outer_grad_mode = [True]
+
+
+def block_fn(*args):
+    """BlockFn.apply that also tells the node whether the caller runs with gradients enabled (a no-grad pass saves nothing: no GELU' side
+    tensor, and with DINOX_QKV_FUSED=1 no packed qkv tensor either)."""
+    prev = _outer_grad_mode[0]
+    _outer_grad_mode[0] = torch.is_grad_enabled()
+    try:
+        return BlockFn.apply(*args)
+    finally:
+        _outer_grad_mode[0] = prev
+
+
 class BlockFn(torch.autograd.Function):
     """One pre-norm transformer block as a single autograd node (reference zoo/arch.py:94-97 with
     Attention :43-54 and Mlp :75-76 inlined):  x1 = x0 + proj(attn(norm1(x0)));  x2 = x1 + fc2(gelu(fc1(norm2(x1)))).
@@ -1007,7 +1053,9 @@ class BlockFn(torch.autograd.Function):
         x0 = _c(x0 if x0.dtype == torch.float32 else x0.float())
         V, N, D = x0.shape
         M = V * N
-        train = any(ctx.needs_input_grad)
+        # needs_input_grad says which inputs COULD take a gradient; under torch.no_grad() (encode(), an evaluation loop over a model whose
+        # parameters still require grad) nothing will ever ask for one: block_fn() notes the caller's grad mode (inside forward it is always off)
+        train = any(ctx.needs_input_grad) and _outer_grad_mode[0]
         if _block_native_ok(dt, x0, wqkv):
             return _block_forward_native(ctx, x0, n1w, n1b, wqkv, bqkv, wproj, bproj, n2w, n2b, w1, b1, w2, b2, heads, eps, pre_ln, next_ln, train)
         ctx.native = False
@@ -1015,8 +1063,11 @@ class BlockFn(torch.autograd.Function):
             xn1, mean1, rstd1 = layernorm_fwd(x0, n1w, n1b, dt, eps)
         else:
             xn1, mean1, rstd1 = pre_ln
-        qkv = gemm(xn1.view(M, D), weight_operand(wqkv, dt), bias=bqkv, out_dtype=dt)
-        o, lse = attention_fwd(qkv.view(V, N, 3 * D), heads)
+        if not train and dt == torch.bfloat16 and _QKV_FUSED and qkv_attention_ok(V, N, heads, D, D):
+            o, qkv, lse = qkv_attention(xn1.view(V, N, D), weight_operand(wqkv, dt), bqkv, heads)      # one launch, no qkv tensor
+        else:
+            qkv = gemm(xn1.view(M, D), weight_operand(wqkv, dt), bias=bqkv, out_dtype=dt)
+            o, lse = attention_fwd(qkv.view(V, N, 3 * D), heads)
         if rowln_ok(M, D, D, dt):
             x1, xn2, mean2, rstd2 = linear_residual_ln(o.view(M, D), weight_operand(wproj, dt), bproj, x0.view(M, D), n2w, n2b, eps, dt)
         else:

@@ -116,7 +116,7 @@ class TransformerBlock(nn.Module):
         proj / fc2 products' epilogues (ops.linear_residual_ln) instead of separate launches.  -> (x_out, (y, mean, rstd))."""
         a, m = self.attn, self.mlp
         nl = (next_norm.weight.detach(), next_norm.bias.detach(), next_norm.eps, next_dtype)
-        out = ops.BlockFn.apply(x, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias,
+        out = ops.block_fn(x, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias,
                                 self.norm2.weight, self.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias,
                                 a.num_heads, self.norm1.eps, pre_ln, nl)
         return out[0], (out[1], out[2], out[3])
@@ -124,7 +124,7 @@ class TransformerBlock(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if self._fusable():      # the whole block as ONE autograd node (ops.BlockFn); weights are read from the sub-modules
             a, m = self.attn, self.mlp
-            return ops.BlockFn.apply(x, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias,
+            return ops.block_fn(x, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias,
                                      self.norm2.weight, self.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias,
                                      a.num_heads, self.norm1.eps)
         # a sub-module was replaced (e.g. LoRA-wrapped): compose the per-op nodes instead

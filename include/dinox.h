@@ -167,6 +167,16 @@ int dinox_softmax_bwd_rows(float* s, float* dp, const float* lse, float scale, i
 int64_t dinox_attention_bwd_ws_bytes(int B, int N, int heads);
 int dinox_attention_bwd(const void* d_o, const void* qkv, const void* o, const float* lse, void* dqkv, void* ws,
                         int B, int N, int heads, int d, int dtype, void* stream);
+/* north_star's "fused QKV projection + multi-head attention" as ONE launch, for passes that keep nothing for a backward (the teacher
+ * of a training step, encode()): qkv = x wqkv^T + bias (zoo/arch.py:46 `self.qkv`) and softmax(q k^T / sqrt(d)) v (:47-52) per
+ * (image, head) without the packed qkv tensor ever reaching HBM.  bf16: x [B*N][D], wqkv [3*heads*d][D], bias fp32 [3*heads*d] or NULL
+ * -> o [B*N][heads*d].  qkv_out ([B*N][3*heads*d]) and lse ([B*heads][N] fp32) are optional outputs (NULL: not written).
+ * dinox_qkv_attention_ok: 1 inside the kernel's envelope (d = 64, 193 <= N <= 224, D % 32 == 0); outside it the entry returns
+ * DINOX_EUNSUPPORTED and the caller composes dinox_gemm + dinox_attention_fwd.  Measured on MI355X it is on a par with those two
+ * launches at ViT-S and slower at ViT-L: dinox_block_forward uses it only when asked to (qkv == NULL). */
+int dinox_qkv_attention_ok(int B, int N, int heads, int d, int D);
+int dinox_qkv_attention_fwd(const void* x, const void* wqkv, const float* bias, void* o, void* qkv_out, float* lse, int B, int N,
+                            int heads, int d, int D, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Patch unfold + token assembly -- replaces the im2col half of nn.Conv2d(3,D,k=p,s=p) and

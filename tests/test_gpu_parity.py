@@ -1674,6 +1674,69 @@ def test_gemm_tn_split_k_is_bit_reproducible(dx, K, M, N, cs):
         assert rel_l2(outs[0][1] - c0, A.double().sum(0)) < 1e-5
 
 
+@pytest.mark.parametrize("B,N,heads,D,bias", [(3, 201, 6, 384, True), (70, 201, 6, 384, True), (2, 224, 2, 96, False), (5, 197, 16, 1024, True),
+                                                 (1, 201, 6, 384, True)])
+def test_qkv_attention_fused_vs_composed_and_fp64(dx, B, N, heads, D, bias):
+    """dinox_qkv_attention_fwd (projection + attention in one launch: the packed qkv never reaches HBM) against (a) fp64 on the same
+    bf16 operands -- qkv rounded to bf16 as the kernel hands it over -- and (b) the two launches it replaces (dinox_gemm +
+    dinox_attention_fwd): the same arithmetic in another summation order, so equal to a bf16 rounding step.  Padded tokens (N < 224),
+    both pair->workgroup mappings (B < 64: pair by pair; B >= 64: one image's heads on one XCD), optional qkv / lse outputs."""
+    ops, _ = dx
+    C = heads * 64
+    g = torch.Generator().manual_seed(B * 1000 + N + D)
+    x = (torch.randn(B, N, D, generator=g) * 0.7).bfloat16().to(DEV)
+    w = (torch.randn(3 * C, D, generator=g) * (1.5 / D ** 0.5)).bfloat16().to(DEV)
+    b = (torch.randn(3 * C, generator=g) * 0.2).to(DEV) if bias else None
+    assert ops.qkv_attention_ok(B, N, heads, D, C) and not ops.qkv_attention_ok(B, 261, heads, D, C) and not ops.qkv_attention_ok(B, N, heads, D, heads * 88)
+    o, qkv, lse = ops.qkv_attention(x, w, b, heads, want_qkv=True, want_lse=True)
+    o2, none_qkv, none_lse = ops.qkv_attention(x, w, b, heads)
+    assert none_qkv is None and none_lse is None and torch.equal(o, o2)                      # the optional outputs change nothing
+    torch.cuda.synchronize()
+    # (a) fp64
+    qkv64 = x.double().reshape(B * N, D) @ w.double().t() + (b.double() if bias else 0.0)
+    assert float((qkv.double().reshape(B * N, 3 * C) - qkv64).abs().max()) <= 2.0 ** -8 * float(qkv64.abs().max()) + 1e-6
+    qr = qkv.double().reshape(B, N, 3, heads, 64).permute(2, 0, 3, 1, 4)                    # what the attention saw: the bf16 hand-over
+    s = qr[0] @ qr[1].transpose(-1, -2) / 8.0
+    ref = (torch.softmax(s, -1) @ qr[2]).permute(0, 2, 1, 3).reshape(B, N, C)
+    assert rel_l2(o.double(), ref) < 4e-3 and float((o.double() - ref).abs().max()) < 2.5e-2 * float(ref.abs().max())
+    assert float((lse.double() - torch.logsumexp(s, -1)).abs().max()) < 2e-3
+    # (b) the composed launches
+    qkv_c = ops.gemm(x.reshape(B * N, D), w, bias=b, out_dtype=torch.bfloat16).reshape(B, N, 3 * C)
+    o_c, lse_c = ops.attention_fwd(qkv_c, heads)
+    assert float((qkv.float() - qkv_c.float()).abs().max()) <= 2.0 ** -7 * float(qkv_c.float().abs().max())
+    assert rel_l2(o.float(), o_c.float()) < 4e-3 and float((lse - lse_c).abs().max()) < 2e-2
+
+
+@pytest.mark.parametrize("native", [True, False])
+def test_no_grad_forward_with_fused_qkv_attention(dx, native, monkeypatch):
+    """DINOX_QKV_FUSED=1: the no-grad forward (the teacher of a step, encode()) runs qkv projection + attention as one launch per block,
+    through dinox_block_forward (qkv == NULL) and through the Python-sequenced block alike; features equal the default path's to bf16
+    rounding, and a training forward (grad enabled) never takes it."""
+    ops, arch = dx
+    torch.manual_seed(5)
+    net = arch.PatchViT(img_size=224, patch=16, dim=128, depth=2, heads=2, scale_aware=False).to(DEV)
+    x = torch.randn(3, 3, 224, 224, device=DEV)
+    monkeypatch.setattr(ops, "_BLOCK_NATIVE", native)
+
+    def fwd(fused, grad):
+        """-> (features, dinox_gemm launches with N = 3 D: the qkv products that ran as launches of their own)"""
+        monkeypatch.setattr(ops, "_QKV_FUSED", fused)
+        t = ops.GemmTimer(every=1 << 20)
+        with t, ops.compute_dtype(torch.bfloat16), (torch.enable_grad() if grad else torch.no_grad()):
+            y = net(x)
+        n_qkv = sum(int(f[10]) for f in (l.split() for l in t.text.splitlines()) if len(f) == 13 and int(f[2]) == 3 * 128 and int(f[3]) == 128)
+        return y, n_qkv
+
+    y0, q0 = fwd(False, False)
+    y1, q1 = fwd(True, False)
+    assert (q0, q1) == (2, 0)                                                         # both blocks: no qkv launch, no qkv tensor
+    assert rel_l2(y1.float(), y0.float()) < 6e-3                                      # (the same sums in another order; often bit-equal at K = 128)
+    y2, q2 = fwd(True, True)                                                          # a forward that will be differentiated keeps qkv
+    assert q2 == 2
+    y2.float().square().mean().backward()
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in net.parameters() if p.requires_grad)
+
+
 @pytest.mark.parametrize("form", ["1", "2", "3"])
 def test_gemm_tn_big_every_tile_form(dx, form, monkeypatch):
     """gemm_bf16_tn_big has three tile shapes (256 x 192, 384 x 128, 256 x 256; the plan picks by kps x TM x TN): each one forced

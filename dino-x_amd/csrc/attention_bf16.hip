@@ -802,11 +802,11 @@ __global__ __launch_bounds__(448) void attn_bwd_fused_bf16(const bf16_t* __restr
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const float p = __builtin_amdgcn_exp2f(st[e] * c2 - L2);
-          st[e] = kt * 32 + acc_row(e, hl) < N ? p * (dp[e] - delta) * sc : 0.f;
+          st[e] = kt * 32 + acc_row(e, hl) < N ? p * (dp[e] - delta) : 0.f;
         }
       } else {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) st[e] = __builtin_amdgcn_exp2f(st[e] * c2 - L2) * (dp[e] - delta) * sc;   // dS^T (scaled)
+        for (int e = 0; e < 16; ++e) st[e] = __builtin_amdgcn_exp2f(st[e] * c2 - L2) * (dp[e] - delta);   // dS^T, UNSCALED: sc multiplies dQ once, below
       }
 #pragma unroll
       for (int ss = 0; ss < 2; ++ss) {
@@ -816,6 +816,12 @@ __global__ __launch_bounds__(448) void attn_bwd_fused_bf16(const bf16_t* __restr
           dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, rd_tr_pair(kimg + ta.off[ss][dt][0] + kt * 4096, kimg + ta.off[ss][dt][1] + kt * 4096),
                                                            dq[dt], 0, 0, 0);
       }
+    }
+    // softmax scale, once per output element instead of once per score (sc = 1/8 at head size 64: exact, the result is bit for bit the same)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      dq[0][e] *= sc;
+      dq[1][e] *= sc;
     }
     // the wave's k, v rows for phase 2 come out of the images (rows >= N repeat row N - 1, like a clamped row load)
     bf16x8 kf[4], vf[4];
@@ -861,7 +867,7 @@ __global__ __launch_bounds__(448) void attn_bwd_fused_bf16(const bf16_t* __restr
           const int e = 4 * g4 + r;
           const float p = __builtin_amdgcn_exp2f(st[e] * c2 - lv[r]);
           st[e] = p;                                                          // P
-          dp[e] = p * (dp[e] - dvv[r]) * sc;                                  // dS (scaled)
+          dp[e] = p * (dp[e] - dvv[r]);                                       // dS, unscaled (sc multiplies dK once, below)
         }
       }
 #pragma unroll
@@ -875,6 +881,11 @@ __global__ __launch_bounds__(448) void attn_bwd_fused_bf16(const bf16_t* __restr
                                                            dk[dt], 0, 0, 0);
         }
       }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      dk[0][e] *= sc;
+      dk[1][e] *= sc;
     }
     prev = pair;
   }

@@ -1955,6 +1955,10 @@ def test_bench_launches_its_own_ranks(dx):
     fired, total = (int(x) for x in d["config"]["grad_buckets_launched_during_backward"].split("/"))
     assert total >= 3 and fired >= total - 1                 # the all-reduces are launched from backward, not after it
     assert set(d["step_ms_split"]) == {"fwd_student", "fwd_teacher", "loss", "bwd", "comm_exposed", "optimiser_tail"}
+    # the line says what the collectives ran on (the driver's 8-GPU record can be checked against DESIGN.md section 5's prediction)
+    c = d["config"]
+    assert c["dist_backend"] == "gloo" and c["rccl_ranks_seen"] == 2 and c["comm_exposed_ms_max_over_ranks"] >= 0.0
+    assert len(c["grad_bucket_bytes"]) == total and sum(c["grad_bucket_bytes"]) == c["grad_bytes_per_step"] and c["centre_allreduce_bytes"] == 4 * 8192
 
 
 def test_gemm_timer_samples_launches_and_prices_families(dx):

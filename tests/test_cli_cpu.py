@@ -132,6 +132,33 @@ def test_slice_cache_behind_png_dataset(cli, tmp_path):
         SliceCache([rows[0].png_path], tmp_path / "other", create=False)
 
 
+def test_slice_cache_file_kinds_and_ragged_shapes(tmp_path):
+    """The cache holds what the dataset's decoder returns, whatever the file is: 16-bit grey as stored, the first channel of an RGB
+    file, the VALUES of an 8-bit file (as np.asarray(.., uint16) would give) -- and slices of different sizes side by side (one entry
+    per file at its own H x W)."""
+    from PIL import Image
+    from dinox.stackcache import SliceCache, decode_png_u16, png_shape
+    g = np.random.default_rng(0)
+    files = []
+    a16 = g.integers(0, 65535, (40, 56), dtype=np.uint16)
+    Image.fromarray(a16).save(tmp_path / "g16.png"); files.append(tmp_path / "g16.png")
+    rgb = g.integers(0, 255, (32, 32, 3), dtype=np.uint8)
+    Image.fromarray(rgb).save(tmp_path / "rgb.png"); files.append(tmp_path / "rgb.png")
+    a8 = g.integers(0, 255, (24, 72), dtype=np.uint8)
+    Image.fromarray(a8).save(tmp_path / "g8.png"); files.append(tmp_path / "g8.png")
+    assert [png_shape(f) for f in files] == [(40, 56), (32, 32), (24, 72)]
+    cache = SliceCache(files, tmp_path / "c")
+    assert cache.total == 40 * 56 + 32 * 32 + 24 * 72 and sorted(cache.shapes) == sorted([(40, 56), (32, 32), (24, 72)])
+    for f, want in zip(files, (a16, rgb[:, :, 0], a8)):
+        got = cache.get(f)
+        assert got.dtype == np.uint16 and got.shape == want.shape and np.array_equal(got, want.astype(np.uint16))
+        assert np.array_equal(np.asarray(decode_png_u16(f)).astype(np.uint16), got)
+    assert cache.filled() == 3 and np.array_equal(cache.get(files[0]), a16) and cache.hits == 1
+    (tmp_path / "bad.png").write_bytes(b"not a png at all, just bytes......")
+    with pytest.raises(ValueError, match="not a PNG"):
+        SliceCache([tmp_path / "bad.png"], tmp_path / "c2")
+
+
 def test_png_dataset_views_and_collate(cli, tmp_path):
     rows = cli._load_index_rows(_write_pngs(tmp_path), require_spacing=True)
     assert len(rows) == 12 and rows[5].spacing_z == 2.0 and rows[0].dataset == "toy"

@@ -44,11 +44,15 @@ def bucketer(rank, world, port, out):
     assert len(bk.buckets) >= 3
     X, Y = toy_data()
     lo, hi = shard_range(8, rank, world)
+    fired = []
     for _ in range(2):                                               # two steps: arm() must reset state
         flat_g.zero_()
         bk.arm()
         ((model(X[lo:hi]) - Y[lo:hi]) ** 2).mean().backward()
+        fired.append(bk.fired_in_backward)
         bk.finish()
+    # DINOX_DP_OVERLAP=0 (A/B on real nodes): nothing leaves from backward, finish() exchanges every bucket -- same sums either way
+    assert fired == ([0, 0] if os.environ.get("DINOX_DP_OVERLAP") == "0" else [len(bk.buckets)] * 2), fired
     if rank == 0:
         np.savez(out, flat=(flat_g / world).numpy(), nbuckets=len(bk.buckets))
     dist.barrier()

@@ -28,10 +28,10 @@ def _free_port():
     return p
 
 
-def _run(which, tmp_path, world=2):
+def _run(which, tmp_path, world=2, env=None):
     port, out = _free_port(), str(tmp_path / "out.npz")
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_dp_workers.py"), which, str(r), str(world), str(port), out],
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=dict(os.environ, **(env or {}))) for r in range(world)]
     logs = []
     for p in procs:
         try:
@@ -45,8 +45,10 @@ def _run(which, tmp_path, world=2):
         return {k: z[k] for k in z.files}
 
 
-def test_bucketed_allreduce_matches_global_batch(tmp_path):
-    got = _run("bucketer", tmp_path)
+@pytest.mark.parametrize("overlap", ["1", "0"])
+def test_bucketed_allreduce_matches_global_batch(tmp_path, overlap):
+    """(DINOX_DP_OVERLAP=0: the buckets are exchanged after backward instead of from it -- the same gradient)"""
+    got = _run("bucketer", tmp_path, env={"DINOX_DP_OVERLAP": overlap})
     from dinox.engine import flatten_parameters
     model = W.toy()
     flat_p, params, offs = flatten_parameters(model)

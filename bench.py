@@ -333,9 +333,33 @@ def main() -> None:
 
     B, L = args.batch_size, args.local_crops
     wl = Workload(dev, rank, model=args.model, B=B, scale_aware=not args.no_scale_aware, L=L, local_size=args.local_size, fp32=args.fp32,
-                  steps_hint=args.steps + args.warmup + 8, graph=args.graph)
+                  steps_hint=args.steps + args.warmup + 8 + (16 if world > 1 else 0), graph=args.graph)
     note(f"model + data resident (world {world}, B {B}/GPU, {'fp32' if args.fp32 else 'bf16'})")
     timer = None if (args.no_kernel_timing or args.graph) else ops.GemmTimer(every=args.time_every)
+    # Data parallel: should the gradient buckets be exchanged FROM backward (overlapped: RCCL's channel workgroups then hold CUs beside the
+    # persistent GEMM / attention kernels, which cost them +35..55 % while they do) or AFTER it (one exposed burst)?  Which is cheaper is a
+    # property of the node, so a few extra warm-up steps time both and every rank keeps the faster -- unless
+    # DINOX_DP_OVERLAP pins it.  Nothing of this runs inside the timed region.
+    dp_probe = None
+    if world > 1 and "DINOX_DP_OVERLAP" not in os.environ:
+        from dinox import dp as _dp
+        probe = {}
+        for mode, flag in (("overlapped", False), ("after_backward", True)):
+            _dp.NO_OVERLAP = flag
+            for _ in range(2):
+                wl.step()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(4):
+                wl.step()
+            barrier()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)                 # (the same number on every rank: the same choice)
+            probe[mode] = float(t) / 4 * 1e3
+        _dp.NO_OVERLAP = probe["after_backward"] < probe["overlapped"]
+        dp_probe = {"ms_per_step_overlapped": round(probe["overlapped"], 3), "ms_per_step_after_backward": round(probe["after_backward"], 3),
+                    "chosen": "after_backward" if _dp.NO_OVERLAP else "overlapped"}
+        note(f"gradient exchange: {dp_probe}")
     dt = timed(wl, args.steps, args.warmup, barrier, note, timer)
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -436,6 +460,8 @@ def main() -> None:
             line["config"]["grad_buckets_launched_during_backward"] = f"{overlapped}/{len(wl.eng.bucketer.buckets)}"
         if dist_info is not None:
             line["config"].update(dist_info)
+        if dp_probe is not None:
+            line["config"]["grad_exchange_probe"] = dp_probe
         default_cfg = args.model == "vit-small" and B == 256 and not L and not args.no_scale_aware and not args.fp32
         if world == 1 and not args.no_secondary and default_cfg:
             wl = None

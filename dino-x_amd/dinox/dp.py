@@ -139,7 +139,7 @@ class GradBucketer:
         self._seen.add(i)
         b = self.buckets[self.bucket_of[i]]
         b.pending -= 1
-        if b.pending == 0 and self.exchange and self.active and not _NO_OVERLAP:
+        if b.pending == 0 and self.exchange and self.active and not NO_OVERLAP:
             self.fired_in_backward += 1
             self.pre_exchange()
             b.work = dist.all_reduce(self.flat[b.lo:b.hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -169,8 +169,9 @@ class GradBucketer:
 # DINOX_DP_OVERLAP=0: every bucket is exchanged from finish(), AFTER backward (one burst on all links, nothing beside the backward kernels).
 # The default overlaps the exchange with backward; on MI355X the persistent GEMM / attention kernels then run beside RCCL's channel
 # workgroups and pay +35..55 % while they do (tools/cotenant_probe.py) -- which of the two is cheaper on a given node is
-# a measurement, and this switch is how to take it (bench.py --gpus N with and without it).
-_NO_OVERLAP = os.environ.get("DINOX_DP_OVERLAP", "1") == "0"
+# a measurement, and this switch is how to take it: bench.py --gpus N times a few warm-up steps both ways and keeps the faster (it sets
+# NO_OVERLAP on every rank alike; DINOX_DP_OVERLAP=0|1 pins it).
+NO_OVERLAP = os.environ.get("DINOX_DP_OVERLAP", "1") == "0"
 
 
 def all_reduce_mean_(t: torch.Tensor, group=None) -> torch.Tensor:

@@ -1761,6 +1761,38 @@ def test_gemm_tn_big_every_tile_form(dx, form, monkeypatch):
     assert rel_l2(outs[0][0], A.double().t() @ B.double()) < 2e-6 and rel_l2(outs[0][1], A.double().sum(0)) < 1e-5
 
 
+@pytest.mark.parametrize("K,M,N", [(9000 + 24, 1096, 520), (8192, 384, 384), (8192 + 40, 1536, 384), (33000, 384, 1152), (12864, 1024, 4096)])
+def test_gemm_tn_big_anti_phase_loop_equals_in_step_loop(dx, K, M, N, monkeypatch):
+    """gemm_bf16_tn_big's K loop runs two wave groups half a step apart (one reads a step's fragments while the other issues its MFMAs);
+    DINOX_TN_PP=0 keeps every wave in step, =1 is the anti-phase loop on the same MFMA shape: the same products added in the same order,
+    bit-equal results, bias gradient included.  The default (=2, v_mfma_f32_16x16x32_bf16: 32 products per instruction instead of 16)
+    differs from them by fp32 rounding only and is bit-reproducible.  Ragged tiles, a K that leaves the last split a handful of steps
+    (or less than one), every tile shape the plan picks."""
+    ops, _ = dx
+    g = torch.Generator().manual_seed(K % 997)
+    A = (torch.randn(K, M, generator=g) * 0.5).bfloat16().to(DEV)
+    B = (torch.randn(K, N, generator=g) * 0.5).bfloat16().to(DEV)
+    outs = {}
+    for pp in ("0", "1", "2", "2 again", None):
+        if pp is None:
+            monkeypatch.delenv("DINOX_TN_PP")
+        else:
+            monkeypatch.setenv("DINOX_TN_PP", pp[0])
+        ops.TRACE_KERNELS = []
+        try:
+            cvec = torch.zeros(M, device=DEV)
+            outs[pp] = (ops.gemm(A, B, transA=True, transB=True, out_dtype=torch.float32, colsum_out=cvec), cvec)
+            assert set(ops.TRACE_KERNELS) == {"gemm_bf16_tn_big"}
+        finally:
+            ops.TRACE_KERNELS = None
+    assert torch.equal(outs["0"][0], outs["1"][0]) and torch.equal(outs["0"][1], outs["1"][1])
+    assert torch.equal(outs["2"][0], outs["2 again"][0]) and torch.equal(outs["2"][1], outs["2 again"][1])
+    assert torch.equal(outs["2"][0], outs[None][0]) and torch.equal(outs["2"][1], outs[None][1])          # (the default)
+    want, wantb = A.double().t() @ B.double(), A.double().sum(0)
+    for pp in ("1", "2"):
+        assert rel_l2(outs[pp][0], want) < 2e-6 and rel_l2(outs[pp][1], wantb) < 1e-5
+
+
 def test_training_steps_are_bit_reproducible(dx):
     """Two runs of three bf16 optimiser steps from the same state end in bit-identical student, teacher, Adam moments and centre:
     no kernel of the step leaves the order of a floating-point sum to the scheduler (round 1: the split-K atomics of the dW products did)."""

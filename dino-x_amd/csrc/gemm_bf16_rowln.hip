@@ -102,6 +102,95 @@ __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void gemm_bf16_rowln(RowLnPar
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   const int nk = p.K / RL_BK, frow = lane & 31, fh = lane >> 5;
+  if constexpr (NS == 4) {
+    // ---- long reductions: two wave groups in anti-phase (the schedule of gemm_bf16_pp.hip / gemm_bf16_tnbig.hip).  Waves 0-3 (rows
+    // 0-63) and 4-7 (rows 64-127) are the two waves of every SIMD; in each barrier interval one group reads the fragments of a whole
+    // K-step (L slot: 10 ds_read_b128, two of its four staging requests, the counted wait that retires step kt + 1) while the other
+    // issues the step's 12 MFMAs (M slot, the other two requests behind them).  Group 1 runs one interval late:
+    //   interval 2 kt: G0 L(kt) | G1 M(kt - 1);   interval 2 kt + 1: G0 M(kt) | G1 L(kt)
+    // Stage kt + 3 goes into the slot of stage kt - 1, whose last reader (G1, L(kt - 1)) finished before the barrier in front of interval
+    // 2 kt.  The steady state is straight-line code; the last three steps (nothing left to request) run a generic copy.
+    const int grp = wr;
+    auto wait_younger = [&](int n) {                            // wave-uniform n (prologue and the last steps only)
+      switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+      }
+    };
+#define RL_SYNC                                                                                                          \
+  {                                                                                                                      \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                   \
+    __builtin_amdgcn_s_barrier();                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                                   \
+  }
+    const int npro = nk < NS - 1 ? nk : NS - 1;
+    for (int s0 = 0; s0 < npro; ++s0) stage(s0, s0);
+    if (npro >= 3) wait_younger(8);
+    else wait_younger((npro - 1) * 4);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (the vector slices written above)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (grp == 1) {
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    bf16x8 fa[4], fb[6];
+    auto read_frags = [&](const char* sa) {
+      const char* sb = sa + RL_ATILE;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int kc = 2 * ks + fh;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int ra = wr * 64 + i * 32 + frow;
+          fa[ks * 2 + i] = *reinterpret_cast<const bf16x8*>(sa + ra * 64 + ((kc ^ ((ra >> 2) & 3)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const int rb = wc * 96 + j * 32 + frow;
+          fb[ks * 3 + j] = *reinterpret_cast<const bf16x8*>(sb + rb * 64 + ((kc ^ ((rb >> 2) & 3)) << 4));
+        }
+      }
+    };
+    auto mma = [&]() {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks * 3 + j], fa[ks * 2 + i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    int slot = 0;                                               // ring slot of stage kt
+    unsigned koff = (unsigned)(NS - 1) * 64;                    // byte offset of stage kt + 3 along K
+    const int nsteady = nk - (NS - 1);
+    for (int kt = 0; kt < nsteady; ++kt) {
+      char* const rs = smem + ((slot + NS - 1) & (NS - 1)) * RL_SLOT;      // slot of stage kt + 3 (= of stage kt - 1)
+      read_frags(smem + slot * RL_SLOT);
+      __builtin_amdgcn_global_load_lds((rl_gbl_void*)(abase + avoff + koff), (rl_lds_void*)(rs + wv * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((rl_gbl_void*)(bbase + bvoff[0] + koff), (rl_lds_void*)(rs + RL_ATILE + wv * 3072), 16, 0, 0);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");          // younger than stage kt + 1: stage kt + 2 and the two requests above
+      RL_SYNC
+      mma();
+      __builtin_amdgcn_global_load_lds((rl_gbl_void*)(bbase + bvoff[1] + koff), (rl_lds_void*)(rs + RL_ATILE + wv * 3072 + 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((rl_gbl_void*)(bbase + bvoff[2] + koff), (rl_lds_void*)(rs + RL_ATILE + wv * 3072 + 2048), 16, 0, 0);
+      RL_SYNC
+      slot = (slot + 1) & (NS - 1);
+      koff += 64;
+    }
+    for (int kt = nsteady > 0 ? nsteady : 0; kt < nk; ++kt) {
+      read_frags(smem + slot * RL_SLOT);
+      if (kt + 1 < nk) wait_younger((nk - 2 - kt) * 4);
+      RL_SYNC
+      mma();
+      if (!(kt + 1 == nk && grp == 1)) RL_SYNC
+      slot = (slot + 1) & (NS - 1);
+    }
+#undef RL_SYNC
+  } else {
   for (int s0 = 0; s0 < NS - 1 && s0 < nk; ++s0) stage(s0, s0);
   for (int kt = 0; kt < nk; ++kt) {
     const int slot = kt & (NS - 1);
@@ -140,6 +229,7 @@ __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void gemm_bf16_rowln(RowLnPar
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);   // [features][tokens]
     }
+  }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                          // every wave has left the ring: it becomes the epilogue's staging area

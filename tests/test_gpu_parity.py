@@ -1206,7 +1206,7 @@ def test_gemm_nt_areg(dx, M, N, K, monkeypatch):
 
 
 @pytest.mark.parametrize("M,K,res,bias", [(1000, 384, True, True), (128 * 5 + 17, 1536, True, True), (77, 384, True, False), (128 * 3 + 70, 384, False, True),
-                                          (4096, 1152, True, True), (128 * 700 + 9, 384, True, True)])
+                                          (4096, 1152, True, True), (128 * 700 + 9, 384, True, True), (300, 608, True, True)])
 @pytest.mark.parametrize("ydt", [torch.bfloat16, torch.float32])
 def test_linear_residual_ln(dx, M, K, res, bias, ydt):
     """dinox_linear_residual_ln (csrc/gemm_bf16_rowln.hip: x = residual + a W^T + bias and y = LayerNorm(x) with the row statistics in

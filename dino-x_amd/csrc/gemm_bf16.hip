@@ -553,6 +553,8 @@ bool gemm_bf16_nt_pp_ok(const GemmParams& p);                                   
 int launch_gemm_bf16_nt_pp(const GemmParams& p, hipStream_t st);
 bool gemm_bf16_nt_pp128_ok(const GemmParams& p);                                                // gemm_bf16_pp128.hip
 int launch_gemm_bf16_nt_pp128(const GemmParams& p, hipStream_t st);
+bool gemm_bf16_nt_pp384_ok(const GemmParams& p);                                                // gemm_bf16_pp384.hip
+int launch_gemm_bf16_nt_pp384(const GemmParams& p, hipStream_t st);
 
 // Which NT products take the persistent ping-pong kernels (gemm_bf16_pp.hip: 256 x 256 tiles, gemm_bf16_pp128.hip: 256 x 128), and which
 // of the two.  DINOX_NT_PP (read per call, so one process can A/B and the tests can force small shapes onto them): 0 = never; 1 = every
@@ -563,6 +565,17 @@ static const char* nt_pp_choice(const GemmParams& p) {
   const int mode = e ? atoi(e) : -1;
   if (mode == 0) return nullptr;
   const bool ok256 = gemm_bf16_nt_pp_ok(p), ok128 = gemm_bf16_nt_pp128_ok(p);
+  {
+    // The full-row tile for N = 384 (gemm_bf16_pp384.hip; DINOX_NT_PP384 read per call: 0 = never, 1 = every product in its envelope,
+    // unset = the measured policy).  tools/pp384_check.py, M = 102 912, interleaved with the 256 x 128 kernel on one box: dX K 1536
+    // 139 -> 118 us, dX K 1152 95 -> 86 (M = 25 728: 46 -> 43, 37 -> 34); K = 384 a tie (43 vs 45); with the fp32 residual epilogue a tie
+    // too (fc2 175 vs 175: its two rounds of tiles run in lockstep, so the 316 MB of residual traffic are not hidden behind K loops).
+    const char* e3 = getenv("DINOX_NT_PP384");
+    const int m3 = e3 ? atoi(e3) : -1;
+    if (m3 != 0 && mode != 2 && mode != 3 && gemm_bf16_nt_pp384_ok(p) &&
+        (m3 > 0 || (p.out_dtype == DINOX_BF16 && !(p.epilogue & DINOX_EPI_RESIDUAL) && p.K >= 768 && p.M >= 8192)))
+      return "gemm_bf16_nt_pp384";
+  }
   if (mode == 2) return ok128 ? "gemm_bf16_nt_pp128" : nullptr;
   if (mode == 3) return ok256 ? "gemm_bf16_nt_pp" : nullptr;
   // a narrow last column tile wastes matrix work on the 256-wide form: N = 384 is 1.5 tiles (and 804 tiles = 3.14 rounds on 256 CUs)
@@ -635,7 +648,7 @@ int64_t gemm_bf16_ws_bytes(const GemmParams& p) {
 int launch_gemm_bf16(const GemmParams& p, hipStream_t st) {
   const char* v = gemm_bf16_variant(p);
   if (!v) return DINOX_EUNSUPPORTED;
-  if (v[10] == 'n' && v[12] == '_') return v[13] == 'p' ? (v[15] == '1' ? launch_gemm_bf16_nt_pp128(p, st) : launch_gemm_bf16_nt_pp(p, st)) : v[13] == 'a' ? launch_gemm_bf16_nt_areg(p, st) : launch_gemm_bf16_nt_glds(p, st);
+  if (v[10] == 'n' && v[12] == '_') return v[13] == 'p' ? (v[15] == '1' ? launch_gemm_bf16_nt_pp128(p, st) : v[15] == '3' ? launch_gemm_bf16_nt_pp384(p, st) : launch_gemm_bf16_nt_pp(p, st)) : v[13] == 'a' ? launch_gemm_bf16_nt_areg(p, st) : launch_gemm_bf16_nt_glds(p, st);
   const int tiles_m = (int)ceil_div(p.M, GB_BM), tiles_n = (int)ceil_div(p.N, GB_BN);
   const int64_t ntile = (int64_t)tiles_m * tiles_n;
   if (ntile > 0x7fffffff || p.batch > 65535) return DINOX_EUNSUPPORTED;

@@ -1,0 +1,263 @@
+// gemm_bf16_pp384.hip -- NT kernel for the products whose output is ONE model row wide: N = 384, bf16 out (ViT-S: the three
+// input-gradient products -- 36 launches and ~3.4 ms of a 36 ms step on gemm_bf16_pp128.hip).
+//
+// Why another tile shape.  The K loops of the 256 x 128 kernel sit on the L2 -> LDS fill rate (48 KiB staged per
+// 4.2 MFLOP, 29 B/clk/CU); a tile that spans the whole 384-column row stages the token operand ONCE instead of once per 128-column tile:
+// 37 KiB per 5.1 MFLOP (a 32-deep K-tile of 208 x 384) -- 1.6 x fewer staged bytes per flop.  And the tile height is chosen for the
+// hot-path row count: 102 912 rows = 512 x 201, so 208-row tiles are 495 tiles = 1.93 rounds of 256 CUs (two rounds, 97 % full), where
+// 256-row tiles are 402 = 1.57 rounds (two rounds, 78 % full: measured 133 us at K = 1536 against 139 on the 256 x 128 kernel).
+//
+// Tile 208 x 384 x 32, ONE tile per workgroup, eight waves 1 (rows) x 8 (columns): a wave owns ALL 208 rows of 48 columns = 13 x 3
+// accumulators of v_mfma_f32_16x16x32_bf16 (156 registers; operands swapped so that a lane holds four consecutive output columns) and
+// keeps a whole K-tile's fragments in registers (13 A + 3 B reads of 16 bytes: 64 registers).  K-tiles of 32 ([208 + 384 rows][32 k],
+// 64-byte rows, 16-byte chunk c of row r at c ^ (3 ((r >> 2) & 1)): conflict-free ds_read_b128 for the operand map UNDER THE
+// INSTRUCTION'S REAL LANE GROUPS ({0-3, 12-15, 20-27}, ...: MI355X_MICROARCH.md, LDS; c ^ ((r >> 2) & 3), the swizzle of an earlier
+// build, is 2-way conflicted there) in a FOUR-slot ring of 37 KiB; K-tile g + 3 is requested during K-tile g (37 buffer_load ... lds
+// instructions of 16 rows: five per wave, two for the last wave).  The two wave groups (waves 0-3 / 4-7, the two waves of every SIMD)
+// run one barrier interval apart, ONE (L, M) slot pair per K-tile as in gemm_bf16_tnbig.hip:
+//   interval 2 g: G0 L(g) | G1 M(g - 1);   interval 2 g + 1: G0 M(g) | G1 L(g)
+// L = 16 fragment reads, the counted wait that retires K-tile g + 1, two requests; M = 39 MFMAs (624 cycles of matrix pipe), the other
+// requests behind them.  The steady state is STRAIGHT-LINE code: every request's descriptor, per-lane offset and LDS offset are set up
+// once; the K offset rides in the instruction's scalar offset (which the range check ignores: the row part, which it must see for rows
+// past M to read as zeros, is in the per-lane offset).  The last three K-tiles (nothing left to request) run a generic copy.
+// Epilogue: the WHOLE tile as bf16 in LDS ([208 rows][784 B]: the ring is free by then), one workgroup barrier, then every thread copies
+// 16-byte pieces of whole rows out (non-temporal): memory sees 768-byte row segments.  fp32 out (fc2: + bias + the fp32 residual stream)
+// takes three slabs of 80 / 64 / 64 rows through the same LDS, the residual pieces requested four at a time ahead of their use.
+// Envelope: N == 384, K % 32 == 0, K >= 128; plain / bias epilogues with bf16 or fp32 out, fp32 residual with fp32 out.
+// Replaces nn.Linear's input-gradient products and fc2 (reference zoo/arch.py:76 and the backward of :46,53,75,76).
+#include <cstdlib>
+#include <type_traits>
+
+#include "common.h"
+#include "gemm_common.h"
+#include "gemm_pp_common.h"
+
+namespace dinox {
+
+constexpr int PR_BM = 208, PR_BN = 384, PR_BK = 32;
+constexpr int PR_RB = PR_BM / 16;                             // 13 row blocks
+constexpr int PR_A_BYTES = PR_BM * PR_BK * 2;                 // 13 KiB
+constexpr int PR_KT_BYTES = (PR_BM + PR_BN) * PR_BK * 2;      // 37 KiB per K-tile buffer
+constexpr int PR_NSLOT = 4;                                   // ring depth: K-tile g + 3 is requested during K-tile g
+constexpr int PR_NREQ = (PR_BM + PR_BN) / 16;                 // 37 requests of 16 rows per K-tile
+constexpr int PR_OROW = PR_BN * 2 + 16;                       // row pitch of the bf16 output image (784 B: rows 4 banks apart)
+constexpr int PR_FROW = PR_BN * 4 + 16;                       // row pitch of an fp32 output slab (1552 B)
+constexpr int PR_LDS = PR_BM * PR_OROW > PR_NSLOT * PR_KT_BYTES ? PR_BM * PR_OROW : PR_NSLOT * PR_KT_BYTES;   // 159.25 KiB (>= 80 rows x 1552 B)
+
+template <int OUT_DT, bool RES>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pp384(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int grp = wv >> 2;
+  const int nk = (int)(p.K / PR_BK);
+  const int64_t m0 = (int64_t)blockIdx.x * PR_BM;
+
+  // ---- fragment reads (v_mfma_f32_16x16x32_bf16: lane l holds row l & 15, k = 8 (l >> 4) .. + 7): 64-byte rows, chunk ^ (3 ((row >> 2) & 1))
+  const int fr = lane & 15, fq = lane >> 4;
+  const unsigned foff = (unsigned)(fr * 64 + ((fq ^ (3 * ((fr >> 2) & 1))) << 4));
+  const unsigned b_rd = (unsigned)(PR_A_BYTES + wv * 3 * 1024) + foff;
+
+  // ---- the request stream: ids 0..12: A rows 16 id .., ids 13..36: B rows 16 (id - 13) ..; wave wv issues ids 5 wv .. 5 wv + 4 (wave 7: two).
+  // Requests 0-2 of a wave lie on one side of the A | B border and requests 3-4 on one side (the border is at wave 2, request 3).
+  const int lrow = lane >> 2;
+  const unsigned lchunk = (unsigned)(((lane & 3) ^ (3 * ((lrow >> 2) & 1))) << 4);
+  unsigned voff[5], ldst[5];
+#pragma unroll
+  for (int q = 0; q < 5; ++q) {
+    const int id = wv * 5 + q;
+    ldst[q] = (unsigned)(id * 1024);
+    voff[q] = id < PR_RB ? (unsigned)((m0 + id * 16 + lrow) * p.lda * 2) + lchunk : (unsigned)(((id - PR_RB) * 16 + lrow) * (int)p.ldb * 2) + lchunk;
+  }
+  const bool lo_a = wv * 5 < PR_RB, hi_a = wv * 5 + 3 < PR_RB;
+  const auto rs_lo = __builtin_amdgcn_make_buffer_rsrc(lo_a ? (void*)p.A : (void*)p.B, 0, lo_a ? (int)(p.M * p.lda * 2) : (int)((int64_t)PR_BN * p.ldb * 2), 0x00020000);
+  const auto rs_hi = __builtin_amdgcn_make_buffer_rsrc(hi_a ? (void*)p.A : (void*)p.B, 0, hi_a ? (int)(p.M * p.lda * 2) : (int)((int64_t)PR_BN * p.ldb * 2), 0x00020000);
+#define PR_DMA(Q, SLOTBASE, KOFF)                                                                                         \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds((Q) < 3 ? rs_lo : rs_hi, (pp_lds_void*)((SLOTBASE) + ldst[Q]), 16, voff[Q], (KOFF), 0, 0)
+
+  pp_f32x4 acc[PR_RB][3];                                       // [row block][column block of the wave's 48]
+#pragma unroll
+  for (int i = 0; i < PR_RB; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc[i][j] = pp_f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 af[PR_RB], bfr[3];
+  auto read_frags = [&](const char* kt) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(kt + b_rd + j * 1024);
+#pragma unroll
+    for (int i = 0; i < PR_RB; ++i) af[i] = *reinterpret_cast<const bf16x8*>(kt + foff + i * 1024);
+  };
+  auto mma = [&]() {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < PR_RB; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+#define PR_SYNC                                                                                                           \
+  {                                                                                                                       \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                    \
+    __builtin_amdgcn_s_barrier();                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                                    \
+  }
+
+  // ---- K loop; NM = this wave's requests per K-tile (5; 2 for wave 7)
+  auto kloop = [&](auto nm_c) {
+    constexpr int NM = decltype(nm_c)::value;
+    // prologue: K-tiles 0, 1, 2 (nk >= 4); the first one is retired before anybody reads
+#pragma unroll
+    for (int b = 0; b < PR_NSLOT - 1; ++b) {
+      char* const sb = smem + b * PR_KT_BYTES;
+#pragma unroll
+      for (int q = 0; q < NM; ++q) PR_DMA(q, sb, b * 64);
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NM) : "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (grp == 1) {                                             // the second group runs one barrier interval behind the first
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    int buf = 0;                                                // ring slot of K-tile g
+    int koff = (PR_NSLOT - 1) * 64;                             // K byte offset of K-tile g + 3
+    const int nsteady = nk - (PR_NSLOT - 1);
+    for (int g = 0; g < nsteady; ++g) {
+      char* const rb = smem + (buf == 0 ? PR_NSLOT - 1 : buf - 1) * PR_KT_BYTES;   // ring slot of K-tile g + 3 (= of K-tile g - 1)
+      read_frags(smem + buf * PR_KT_BYTES);
+      // K-tile g + 1 must have landed before the barrier in front of its first read; younger: K-tile g + 2
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NM) : "memory");
+      PR_DMA(0, rb, koff);
+      PR_DMA(1, rb, koff);
+      PR_SYNC
+      mma();
+      if constexpr (NM == 5) {
+        PR_DMA(2, rb, koff);
+        PR_DMA(3, rb, koff);
+        PR_DMA(4, rb, koff);
+      }
+      PR_SYNC
+      buf = buf == PR_NSLOT - 1 ? 0 : buf + 1;
+      koff += 64;
+    }
+    for (int g = nsteady; g < nk; ++g) {                        // the last three K-tiles: nothing left to request
+      read_frags(smem + buf * PR_KT_BYTES);
+      if (g + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NM) : "memory");
+      else if (g + 1 < nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      PR_SYNC
+      mma();
+      if (!(g + 1 == nk && grp == 1)) PR_SYNC
+      buf = buf == PR_NSLOT - 1 ? 0 : buf + 1;
+    }
+  };
+  if (wv * 5 + 4 < PR_NREQ) kloop(std::integral_constant<int, 5>{});
+  else kloop(std::integral_constant<int, PR_NREQ - 35>{});
+#undef PR_DMA
+
+  // ---- epilogue
+  PR_SYNC                                                       // every wave is past its last read of the ring
+  const bool hb = (p.epilogue & DINOX_EPI_BIAS) != 0;
+  const float alpha = p.alpha;
+  float4 bias[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) bias[j] = hb ? *reinterpret_cast<const float4*>(p.bias + wv * 48 + j * 16 + fq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const int rows = (int)(p.M - m0 < PR_BM ? p.M - m0 : PR_BM);
+  if constexpr (OUT_DT == DINOX_BF16) {
+    // the WHOLE tile as bf16 in LDS ([208 rows][784 B]), one barrier, then 16-byte pieces of whole rows out
+    char* const orow = smem + fr * PR_OROW + (wv * 48 + fq * 4) * 2;
+#pragma unroll
+    for (int i = 0; i < PR_RB; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const pp_f32x4 v = acc[i][j];
+        uint2 pk;
+        pk.x = pp_pack2(v[0] * alpha + bias[j].x, v[1] * alpha + bias[j].y);
+        pk.y = pp_pack2(v[2] * alpha + bias[j].z, v[3] * alpha + bias[j].w);
+        *reinterpret_cast<uint2*>(orow + i * 16 * PR_OROW + j * 32) = pk;
+      }
+    PR_SYNC
+    char* const cbase = (char*)p.C + m0 * p.ldc * 2;
+    const int npiece = rows * 48;                               // 16-byte pieces of the tile's valid rows
+    for (int u = (int)threadIdx.x; u < npiece; u += 512) {
+      const int r = u / 48, c = u - r * 48;
+      const pp_u32x4 v = *reinterpret_cast<const pp_u32x4*>(smem + r * PR_OROW + c * 16);
+      __builtin_nontemporal_store(v, reinterpret_cast<pp_u32x4*>(cbase + (int64_t)r * p.ldc * 2 + c * 16));
+    }
+  } else {
+    // fp32 out (+ fp32 residual: the residual stream): the tile passes through LDS in three slabs of 5 + 4 + 4 row blocks ([80 rows][1552 B]);
+    // a slab's copy-out requests its residual pieces four at a time before it touches them (whole 1536-byte rows either way)
+    char* const orow = smem + fr * PR_FROW + (wv * 48 + fq * 4) * 4;
+    auto slab = [&](auto ib_c, auto nb_c) {
+      constexpr int IB = decltype(ib_c)::value, NB = decltype(nb_c)::value;
+#pragma unroll
+      for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const pp_f32x4 v = acc[IB + i][j];
+          *reinterpret_cast<pp_f32x4*>(orow + i * 16 * PR_FROW + j * 64) =
+              pp_f32x4{v[0] * alpha + bias[j].x, v[1] * alpha + bias[j].y, v[2] * alpha + bias[j].z, v[3] * alpha + bias[j].w};
+        }
+      PR_SYNC
+      const int r0 = IB * 16;
+      const int vrows = rows - r0 < 0 ? 0 : (rows - r0 < NB * 16 ? rows - r0 : NB * 16);
+      const int npiece = vrows * 96;                            // 16-byte pieces of the slab's valid rows
+      char* const cbase = (char*)p.C + (m0 + r0) * p.ldc * 4;
+      const char* const rbase = RES ? (const char*)p.residual + (m0 + r0) * p.ldr * 4 : nullptr;
+      constexpr int IT = NB * 16 * 96 / 512;                    // 15 or 12 pieces per thread
+#pragma unroll
+      for (int it0 = 0; it0 < IT; it0 += 4) {
+        pp_f32x4 rr[4];
+        if (RES) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int u = (int)threadIdx.x + (it0 + k) * 512;
+            const int r = u / 96, c = u - r * 96;
+            rr[k] = (it0 + k < IT && u < npiece) ? *reinterpret_cast<const pp_f32x4*>(rbase + (int64_t)r * p.ldr * 4 + c * 16) : pp_f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int u = (int)threadIdx.x + (it0 + k) * 512;
+          const int r = u / 96, c = u - r * 96;
+          if (it0 + k < IT && u < npiece) {
+            pp_f32x4 v = *reinterpret_cast<const pp_f32x4*>(smem + r * PR_FROW + c * 16);
+            if (RES) v += rr[k];
+            *reinterpret_cast<pp_f32x4*>(cbase + (int64_t)r * p.ldc * 4 + c * 16) = v;
+          }
+        }
+      }
+      PR_SYNC                                                   // the slab is overwritten by the next one
+    };
+    slab(std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});
+    slab(std::integral_constant<int, 5>{}, std::integral_constant<int, 4>{});
+    slab(std::integral_constant<int, 9>{}, std::integral_constant<int, 4>{});
+  }
+#undef PR_SYNC
+}
+
+bool gemm_bf16_nt_pp384_ok(const GemmParams& p) {
+  if (!pp_envelope_ok(p, PR_BK) || p.N != PR_BN || p.K < 4 * PR_BK) return false;
+  if (p.epilogue & (DINOX_EPI_GELU | DINOX_EPI_DGELU)) return false;
+  if ((p.epilogue & DINOX_EPI_RESIDUAL) && p.out_dtype != DINOX_F32) return false;      // (the residual stream is fp32)
+  if ((p.M + PR_BM) * p.ldc * 4 >= ((int64_t)1 << 40)) return false;
+  return (p.M + PR_BM) * p.lda * 2 < ((int64_t)1 << 31) && (int64_t)PR_BN * p.ldb * 2 < ((int64_t)1 << 31);      // buffer descriptors, 32-bit offsets
+}
+
+int launch_gemm_bf16_nt_pp384(const GemmParams& p, hipStream_t st) {
+  const int64_t units = ceil_div(p.M, (int64_t)PR_BM);
+  if (units > 0x3fffffff) return DINOX_EUNSUPPORTED;
+#define PR_L(OUT, RES)                                                                                                    \
+  do {                                                                                                                    \
+    auto kern = gemm_bf16_nt_pp384<OUT, RES>;                                                                             \
+    if (int rc = reserve_lds(reinterpret_cast<const void*>(kern), PR_LDS, "gemm_bf16_nt_pp384")) return rc;               \
+    hipLaunchKernelGGL(kern, dim3((unsigned)units), dim3(512), PR_LDS, st, p);                                            \
+  } while (0)
+  if (p.out_dtype == DINOX_BF16) PR_L(DINOX_BF16, false);
+  else if (p.epilogue & DINOX_EPI_RESIDUAL) PR_L(DINOX_F32, true);
+  else PR_L(DINOX_F32, false);
+#undef PR_L
+  return check_launch("gemm_bf16_nt_pp384");
+}
+
+}  // namespace dinox

@@ -126,7 +126,8 @@ def test_gemm_dispatch_by_shape(monkeypatch):
     assert name(T, 1536, 384, epi=EPI_BIAS | EPI_GELU | EPI_AUXGRAD, aux=0x60000) == "gemm_bf16_nt_areg"                  # fc1: VALU-bound either way
     assert name(T, 1536, 384, epi=EPI_DGELU | EPI_AUXGRAD, aux=0x60000) == "gemm_bf16_nt_pp"                              # GELU' product
     assert name(T, 384, 1536, epi=EPI_BIAS | EPI_RESIDUAL, out=F32, res=0x50000) == "gemm_bf16_nt_pp128"                  # fc2: 256 x 128 tiles
-    assert name(T, 384, 1152) == "gemm_bf16_nt_pp128" and name(T, 384, 1536) == "gemm_bf16_nt_pp128"                      # dX of qkv / fc1
+    assert name(T, 384, 1152) == "gemm_bf16_nt_pp384" and name(T, 384, 1536) == "gemm_bf16_nt_pp384"                      # dX of qkv / fc1: full-row 208 x 384 tiles
+    assert name(T, 384, 1536, out=F32) == "gemm_bf16_nt_pp128" and name(4096, 384, 1536) == "gemm_bf16_nt_glds"           # (bf16 out, a chip's worth of rows)
     assert name(T, 384, 384) == "gemm_bf16_nt_pp128" and name(T // 4, 384, 384) == "gemm_bf16_nt_areg"                    # dX of proj: a full chip only
     assert name(T, 384, 384, epi=EPI_BIAS | EPI_RESIDUAL, out=F32, res=0x50000) == "gemm_bf16_nt_areg"                    # proj without the fused LayerNorm
     assert name(T // 2, 4096, 1024, epi=EPI_GELU | EPI_AUXGRAD, aux=0x60000) == "gemm_bf16_nt_pp"                         # ViT-L fc1

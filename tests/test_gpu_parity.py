@@ -1375,17 +1375,51 @@ def test_gemm_nt_pp(dx, M, N, K, mode, monkeypatch):
     close(ops.gemm(Ad, Bd, bias=bias.to(DEV), residual=res.to(DEV), out_dtype=torch.float32), y, 2e-6, 2e-5, "pp vs the 128 x 128 kernels")
 
 
-@pytest.mark.parametrize("case", ["qkv", "fc2", "dact", "dx"])
+@pytest.mark.parametrize("M,K", [(4096, 128), (4096 + 17, 384), (5000, 1152), (208 * 20 + 207, 1536), (208 * 21 + 1, 160), (208 * 30, 384), (90, 256), (70000, 768)])
+def test_gemm_nt_pp384(dx, M, K, monkeypatch):
+    """The full-row kernel for N = 384 (csrc/gemm_bf16_pp384.hip: 208 x 384 tiles, one per workgroup, a wave owns all 208 rows of 48
+    columns), forced onto small and ragged shapes (DINOX_NT_PP384=1): plain and bias with bf16 and fp32 out, the fp32 residual
+    epilogue (three slabs through LDS), against fp64 on the same bf16 operands -- last tiles of 1 .. 207 rows (rows past M read as zeros
+    through the buffer descriptor and are never stored), a single partial tile, four to 48 K-tiles (the three-K-tile tail on its own
+    at K = 128) -- every launch repeated bit for bit, and equal to the kernels it replaces up to the summation order of the K loop."""
+    ops, _ = dx
+    monkeypatch.setenv("DINOX_NT_PP384", "1")
+    g = torch.Generator().manual_seed(M + K)
+    A, B = (torch.randn(M, K, generator=g) * 0.5).bfloat16(), (torch.randn(384, K, generator=g) * (6.0 / math.sqrt(K))).bfloat16()
+    bias, res = torch.randn(384, generator=g), torch.randn(M, 384, generator=g)
+    Ad, Bd, bd, rd = A.to(DEV), B.to(DEV), bias.to(DEV), res.to(DEV)
+    ref = A.double() @ B.double().t()
+    runs = {"plain": lambda: ops.gemm(Ad, Bd), "bias": lambda: ops.gemm(Ad, Bd, bias=bd), "f32": lambda: ops.gemm(Ad, Bd, out_dtype=torch.float32),
+            "bias_res": lambda: ops.gemm(Ad, Bd, bias=bd, residual=rd, out_dtype=torch.float32), "res": lambda: ops.gemm(Ad, Bd, residual=rd, out_dtype=torch.float32)}
+    out = {}
+    ops.TRACE_KERNELS = []
+    try:
+        for k, fn in runs.items():
+            out[k] = fn()
+            assert torch.equal(fn(), out[k]), k
+        assert set(ops.TRACE_KERNELS) == {"gemm_bf16_nt_pp384"} and len(ops.TRACE_KERNELS) == 10, ops.TRACE_KERNELS
+    finally:
+        ops.TRACE_KERNELS = None
+    assert rel_l2(out["plain"].float(), ref) < 3e-3 and rel_l2(out["bias"].float(), ref + bias.double()) < 3e-3
+    close(out["f32"], ref, 1e-5, 1e-4, "plain fp32 out")
+    close(out["bias_res"], ref + bias.double() + res.double(), 1e-5, 1e-4, "bias + residual, fp32 out")
+    close(out["res"], ref + res.double(), 1e-5, 1e-4, "residual, fp32 out")
+    monkeypatch.setenv("DINOX_NT_PP384", "0")
+    close(ops.gemm(Ad, Bd, bias=bd, residual=rd, out_dtype=torch.float32), out["bias_res"], 2e-6, 2e-5, "pp384 vs the kernels it replaces")
+
+
+@pytest.mark.parametrize("case", ["qkv", "fc2", "dact", "dx", "dx384"])
 def test_gemm_nt_pp_full_size_repeatable(dx, case, monkeypatch):
     """BASELINE size (M = 512 views x 201 tokens) through the ping-pong kernels as the DEFAULT policy dispatches them (qkv and the GELU'
-    product on 256 x 256 tiles, fc2 with its fp32 residual and the K = 1152 dX product on 256 x 128 tiles), 60 launches back to back:
+    product on 256 x 256 tiles, fc2 with its fp32 residual and the K = 384 dX product on 256 x 128 tiles, the K = 1152 dX product on the
+    full-row 208 x 384 tiles of gemm_bf16_pp384.hip), 60 launches back to back:
     no atomics, so every launch must reproduce the first bit for bit (a missed wait on a landed K-tile, a request overtaking a read
     or a staging tile overwritten too early shows up as a sporadic difference), and sampled rows must match fp64."""
     ops, _ = dx
     monkeypatch.delenv("DINOX_NT_PP", raising=False)
     g = torch.Generator(device=DEV).manual_seed(1)
     M = 512 * 201
-    N, K = {"qkv": (1152, 384), "fc2": (384, 1536), "dact": (1536, 384), "dx": (384, 1152)}[case]
+    N, K = {"qkv": (1152, 384), "fc2": (384, 1536), "dact": (1536, 384), "dx": (384, 1152), "dx384": (384, 384)}[case]
     A = (torch.randn(M, K, device=DEV, generator=g) * 0.5).bfloat16()
     B = (torch.randn(N, K, device=DEV, generator=g) * 0.5).bfloat16()
     bias = torch.randn(N, device=DEV, generator=g)
@@ -1402,7 +1436,8 @@ def test_gemm_nt_pp_full_size_repeatable(dx, case, monkeypatch):
     ops.TRACE_KERNELS = []
     try:
         first = run()
-        assert ops.TRACE_KERNELS == ["gemm_bf16_nt_pp" if case in ("qkv", "dact") else "gemm_bf16_nt_pp128"], ops.TRACE_KERNELS
+        want = {"qkv": "gemm_bf16_nt_pp", "dact": "gemm_bf16_nt_pp", "fc2": "gemm_bf16_nt_pp128", "dx": "gemm_bf16_nt_pp384", "dx384": "gemm_bf16_nt_pp128"}[case]
+        assert ops.TRACE_KERNELS == [want], ops.TRACE_KERNELS
     finally:
         ops.TRACE_KERNELS = None
     for _ in range(60):

@@ -34,6 +34,8 @@
 
 namespace dinox {
 
+typedef unsigned pr_u32x2 __attribute__((ext_vector_type(2)));
+
 constexpr int PR_BM = 208, PR_BN = 384, PR_BK = 32;
 constexpr int PR_RB = PR_BM / 16;                             // 13 row blocks
 constexpr int PR_A_BYTES = PR_BM * PR_BK * 2;                 // 13 KiB
@@ -44,8 +46,18 @@ constexpr int PR_OROW = PR_BN * 2 + 16;                       // row pitch of th
 constexpr int PR_FROW = PR_BN * 4 + 16;                       // row pitch of an fp32 output slab (1552 B)
 constexpr int PR_LDS = PR_BM * PR_OROW > PR_NSLOT * PR_KT_BYTES ? PR_BM * PR_OROW : PR_NSLOT * PR_KT_BYTES;   // 159.25 KiB (>= 80 rows x 1552 B)
 
-template <int OUT_DT, bool RES>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pp384(GemmParams p) {
+// LayerNorm behind the product (gemm_bf16_rowln.hip's contract: x = residual + a W^T + bias in fp32, y = LayerNorm(x) in bf16, row statistics)
+struct PpLnExtra {
+  const float* gamma;    // [384]
+  const float* beta;     // [384]
+  void* y;               // [M][384] bf16
+  float* mean;           // [M]
+  float* rstd;           // [M]
+  float eps;
+};
+
+template <int OUT_DT, bool RES, bool LN>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pp384(GemmParams p, PpLnExtra ln) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -184,6 +196,93 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pp384(GemmParams p) {
       const pp_u32x4 v = *reinterpret_cast<const pp_u32x4*>(smem + r * PR_OROW + c * 16);
       __builtin_nontemporal_store(v, reinterpret_cast<pp_u32x4*>(cbase + (int64_t)r * p.ldc * 2 + c * 16));
     }
+  } else if constexpr (LN) {
+    // x = product + bias (+ residual) in fp32 AND y = LayerNorm(x) in bf16 with the row statistics.  The tile passes through LDS in three
+    // slabs of 5 + 4 + 4 row blocks ([80 rows][1552 B]); behind the slab's barrier HALF A WAVE owns a row (32 lanes x three 16-byte pieces:
+    // whole 512-byte segments of the row in LDS, in the residual stream, in x and -- as 8-byte pieces -- in y), two rows per wave in
+    // flight, 10 or 8 rows per wave and slab.  The residual pieces of ALL the wave's rows of a slab are requested before the slab is
+    // written (their latency hides behind the LDS write and the barrier); mean and M2 by two passes over the row's 12 registers per lane
+    // (exact: no E[x^2] - mean^2) and five exchange steps inside the half-wave.  x and y leave by NON-TEMPORAL stores: measured on the
+    // kernel that reads y next (fc1 272 -> 263 us, qkv 125 -> 117 us behind this one; plain stores leave it nothing to find in the
+    // memory-side cache).
+    float* const gb = reinterpret_cast<float*>(smem + 80 * PR_FROW);
+    if (threadIdx.x < PR_BN) {
+      gb[threadIdx.x] = ln.gamma[threadIdx.x];
+      gb[PR_BN + threadIdx.x] = ln.beta[threadIdx.x];
+    }
+    const bool has_res = p.residual != nullptr;
+    const int hl = lane & 31, hh = lane >> 5;
+    char* const orow = smem + fr * PR_FROW + (wv * 48 + fq * 4) * 4;
+    auto slab = [&](auto ib_c, auto nb_c) {
+      constexpr int IB = decltype(ib_c)::value, NB = decltype(nb_c)::value;
+      constexpr int NP = NB;                                    // row pairs per wave: 16 NB rows / 8 waves / 2
+      const int r0 = IB * 16;
+      pp_f32x4 rr[NP][3];
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+        const int row = r0 + wv + 16 * q + 8 * hh;
+        const bool ok = has_res && row < rows;
+        const char* rp = (const char*)p.residual + ((m0 + (ok ? row : 0)) * p.ldr + hl * 4) * 4;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) rr[q][k] = ok ? *reinterpret_cast<const pp_f32x4*>(rp + k * 512) : pp_f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const pp_f32x4 v = acc[IB + i][j];
+          *reinterpret_cast<pp_f32x4*>(orow + i * 16 * PR_FROW + j * 64) =
+              pp_f32x4{v[0] * alpha + bias[j].x, v[1] * alpha + bias[j].y, v[2] * alpha + bias[j].z, v[3] * alpha + bias[j].w};
+        }
+      PR_SYNC
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+        const int lr = wv + 16 * q + 8 * hh, row = r0 + lr;
+        pp_f32x4 x[3];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          x[k] = *reinterpret_cast<const pp_f32x4*>(smem + lr * PR_FROW + hl * 16 + k * 512) + rr[q][k];
+          s += (x[k][0] + x[k][1]) + (x[k][2] + x[k][3]);
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        const float mean = s * (1.0f / PR_BN);
+        float m2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float d = x[k][e] - mean;
+            m2 += d * d;
+          }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) m2 += __shfl_xor(m2, o, 64);
+        const float rstd = rsqrtf(m2 * (1.0f / PR_BN) + ln.eps);
+        if (row < rows) {
+          char* const xp = (char*)p.C + ((m0 + row) * p.ldc + hl * 4) * 4;
+          char* const yp = (char*)ln.y + ((m0 + row) * (int64_t)PR_BN + hl * 4) * 2;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const pp_f32x4 g4 = *reinterpret_cast<const pp_f32x4*>(gb + hl * 4 + k * 128);
+            const pp_f32x4 b4 = *reinterpret_cast<const pp_f32x4*>(gb + PR_BN + hl * 4 + k * 128);
+            __builtin_nontemporal_store(x[k], reinterpret_cast<pp_f32x4*>(xp + k * 512));
+            uint2 pk;
+            pk.x = pp_pack2((x[k][0] - mean) * rstd * g4[0] + b4[0], (x[k][1] - mean) * rstd * g4[1] + b4[1]);
+            pk.y = pp_pack2((x[k][2] - mean) * rstd * g4[2] + b4[2], (x[k][3] - mean) * rstd * g4[3] + b4[3]);
+            __builtin_nontemporal_store(pr_u32x2{pk.x, pk.y}, reinterpret_cast<pr_u32x2*>(yp + k * 256));
+          }
+          if (hl == 0) {
+            ln.mean[m0 + row] = mean;
+            ln.rstd[m0 + row] = rstd;
+          }
+        }
+      }
+      PR_SYNC                                                   // the slab is overwritten by the next one
+    };
+    slab(std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});
+    slab(std::integral_constant<int, 5>{}, std::integral_constant<int, 4>{});
+    slab(std::integral_constant<int, 9>{}, std::integral_constant<int, 4>{});
   } else {
     // fp32 out (+ fp32 residual: the residual stream): the tile passes through LDS in three slabs of 5 + 4 + 4 row blocks ([80 rows][1552 B]);
     // a slab's copy-out requests its residual pieces four at a time before it touches them (whole 1536-byte rows either way)
@@ -249,15 +348,40 @@ int launch_gemm_bf16_nt_pp384(const GemmParams& p, hipStream_t st) {
   if (units > 0x3fffffff) return DINOX_EUNSUPPORTED;
 #define PR_L(OUT, RES)                                                                                                    \
   do {                                                                                                                    \
-    auto kern = gemm_bf16_nt_pp384<OUT, RES>;                                                                             \
+    auto kern = gemm_bf16_nt_pp384<OUT, RES, false>;                                                                      \
     if (int rc = reserve_lds(reinterpret_cast<const void*>(kern), PR_LDS, "gemm_bf16_nt_pp384")) return rc;               \
-    hipLaunchKernelGGL(kern, dim3((unsigned)units), dim3(512), PR_LDS, st, p);                                            \
+    hipLaunchKernelGGL(kern, dim3((unsigned)units), dim3(512), PR_LDS, st, p, PpLnExtra{});                               \
   } while (0)
   if (p.out_dtype == DINOX_BF16) PR_L(DINOX_BF16, false);
   else if (p.epilogue & DINOX_EPI_RESIDUAL) PR_L(DINOX_F32, true);
   else PR_L(DINOX_F32, false);
 #undef PR_L
   return check_launch("gemm_bf16_nt_pp384");
+}
+
+// The product + LayerNorm form (called by dinox_linear_residual_ln, gemm_bf16_rowln.hip): y bf16, N = 384, the envelope above.
+bool gemm_bf16_nt_pp384_ln_ok(int64_t M, int K) {
+  return K >= 4 * PR_BK && K % PR_BK == 0 && M >= 1 && (M + PR_BM) * (int64_t)K * 2 < ((int64_t)1 << 31) && (int64_t)PR_BN * K * 2 < ((int64_t)1 << 31);
+}
+
+int launch_gemm_bf16_nt_pp384_ln(const void* a, const void* w, const float* bias, const float* residual, float* x_out, const float* gamma,
+                                 const float* beta, float eps, void* y, float* mean, float* rstd, int64_t M, int K, hipStream_t st) {
+  GemmParams p{};
+  p.A = a; p.B = w; p.C = x_out;
+  p.M = M; p.N = PR_BN; p.K = K;
+  p.lda = K; p.ldb = K; p.ldc = PR_BN;
+  p.batch = 1;
+  p.in_dtype = DINOX_BF16; p.out_dtype = DINOX_F32;
+  p.epilogue = (bias ? DINOX_EPI_BIAS : 0) | (residual ? DINOX_EPI_RESIDUAL : 0);
+  p.alpha = 1.0f;
+  p.bias = bias; p.residual = residual; p.ldr = PR_BN;
+  const PpLnExtra ln{gamma, beta, y, mean, rstd, eps};
+  const int64_t units = ceil_div(M, (int64_t)PR_BM);
+  if (units > 0x3fffffff) return DINOX_EUNSUPPORTED;
+  auto kern = gemm_bf16_nt_pp384<DINOX_F32, true, true>;
+  if (int rc = reserve_lds(reinterpret_cast<const void*>(kern), PR_LDS, "gemm_bf16_nt_pp384")) return rc;
+  hipLaunchKernelGGL(kern, dim3((unsigned)units), dim3(512), PR_LDS, st, p, ln);
+  return check_launch("gemm_bf16_nt_pp384(ln)");
 }
 
 }  // namespace dinox

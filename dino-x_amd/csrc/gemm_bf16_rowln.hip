@@ -23,6 +23,8 @@
 // + 96 sum (mean_w - mean)^2).  Global traffic of the epilogue (residual in, x out, y out) passes through a 4-KiB per-wave LDS tile so
 // that memory sees whole 128-byte lines (second version; the first let every lane load / store its own 16-byte pieces: 32 rows x 32
 // bytes per instruction, 49 of 164 us for the residual loads alone).
+#include <cstdlib>
+
 #include "common.h"
 #include "gemm_common.h"
 
@@ -372,6 +374,12 @@ __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void gemm_bf16_rowln(RowLnPar
 
 }  // namespace dinox
 
+namespace dinox {
+bool gemm_bf16_nt_pp384_ln_ok(int64_t M, int K);                                                   // gemm_bf16_pp384.hip
+int launch_gemm_bf16_nt_pp384_ln(const void* a, const void* w, const float* bias, const float* residual, float* x_out, const float* gamma,
+                                 const float* beta, float eps, void* y, float* mean, float* rstd, int64_t M, int K, hipStream_t st);
+}  // namespace dinox
+
 using namespace dinox;
 
 extern "C" int dinox_linear_residual_ln_ok(int64_t M, int N, int K) {
@@ -391,6 +399,14 @@ extern "C" int dinox_linear_residual_ln(const void* a, const void* w, const floa
   RowLnParams p{(const bf16_t*)a, (const bf16_t*)w, bias, residual, x_out, gamma, beta, y, mean, rstd, M, K, eps};
   const unsigned tiles = (unsigned)ceil_div(M, (int64_t)RL_BM);
   hipStream_t st = as_stream(stream);
+  {
+    // The full-row 208 x 384 kernel with the LayerNorm epilogue (gemm_bf16_pp384.hip) for bf16 y on a chip's worth of rows.
+    // DINOX_ROWLN_PP (read per call): 0 = never, 1 = every shape in its envelope (tests), unset = M >= 8192.
+    const char* e = getenv("DINOX_ROWLN_PP");
+    const int mode = e ? atoi(e) : -1;
+    if (y_dtype == DINOX_BF16 && mode != 0 && gemm_bf16_nt_pp384_ln_ok(M, K) && (mode > 0 || M >= 8192))
+      return launch_gemm_bf16_nt_pp384_ln(a, w, bias, residual, x_out, gamma, beta, eps, y, mean, rstd, M, K, st);
+  }
 #define RL_LAUNCH(YDT, NS)                                                                                                        \
   do {                                                                                                                            \
     if (int rc = reserve_lds(reinterpret_cast<const void*>(gemm_bf16_rowln<YDT, NS>), rl_lds(NS), "linear_residual_ln")) return rc; \

@@ -456,17 +456,21 @@ def layernorm_fwd(x: Tensor, w: Tensor, b: Tensor, out_dtype: torch.dtype, eps: 
     return y, mean, rstd
 
 
+_ROWLN_PP = os.environ.get("DINOX_ROWLN_PP")    # "0": never the full-row kernel's LayerNorm epilogue (the library reads it per call too)
 _ROWLN = os.environ.get("DINOX_ROWLN")          # "1": every width-384 product, "0": none, unset: the short reductions (proj) only
 
 
-def rowln_ok(M: int, N: int, K: int, dt: torch.dtype) -> bool:
-    """Should this product + the LayerNorm behind it run as ONE launch (csrc/gemm_bf16_rowln.hip; bf16 mode, N = 384)?
-    Measured on MI355X at the hot-path shape (M = 102 912), with the epilogue traffic staged through LDS as whole 128-byte lines:
-    proj + LN 136 us fused against 95 + 52 us for the two launches -> on by default for short reductions (K <= 576);
-    fc2 + LN 272 us against 213 + 52 us (its two-slot 128 x 384 K loop alone takes 185 us at K = 1536) -> off unless DINOX_ROWLN=1."""
+def rowln_ok(M: int, N: int, K: int, dt: torch.dtype, y_dtype: Optional[torch.dtype] = None) -> bool:
+    """Should this product + the LayerNorm behind it run as ONE launch (bf16 mode, N = 384)?  Measured on MI355X at the hot-path shape
+    (M = 102 912):
+      * csrc/gemm_bf16_pp384.hip's LayerNorm epilogue (bf16 y, M >= 8192: 208 x 384 full-row tiles; DINOX_ROWLN_PP=0 disables):
+        proj + LN 103 us against 85 + 44 us for the two launches; fc2 + LN 206 us against 177 + 44 -> both fused;
+      * csrc/gemm_bf16_rowln.hip (128 x 384 tiles: fp32 y, small M): proj + LN 130 us against 85 + 44 -> fused for short reductions
+        (K <= 576); fc2 + LN 256 us against 177 + 44 -> not fused unless DINOX_ROWLN=1."""
     if dt != torch.bfloat16 or _ROWLN == "0" or not lib.dinox_linear_residual_ln_ok(M, N, K):
         return False
-    return _ROWLN == "1" or K <= 576
+    full_row = _ROWLN_PP != "0" and M >= 8192 and (y_dtype or dt) == torch.bfloat16 and K >= 128
+    return _ROWLN == "1" or K <= 576 or (full_row and os.environ.get("DINOX_ROWLN_FC2") != "0")
 
 
 def linear_residual_ln(a: Tensor, w: Tensor, bias: Optional[Tensor], residual: Optional[Tensor], gamma: Tensor, beta: Tensor, eps: float,
@@ -941,7 +945,7 @@ def _block_forward_native(ctx, x0, n1w, n1b, wqkv, bqkv, wproj, bproj, n2w, n2b,
         yn, mn, rn = torch.empty((V, N, D), dtype=ydt, device=dev), f32(M), f32(M)
         a.next_g, a.next_b, a.next_eps, a.next_dtype = _p(next_ln[0]), _p(next_ln[1]), next_ln[2], _code(ydt)
         a.yn, a.meann, a.rstdn = _p(yn), _p(mn), _p(rn)
-        a.fuse_fc2_ln = int(rowln_ok(M, D, H, dt))
+        a.fuse_fc2_ln = int(rowln_ok(M, D, H, dt, ydt))
         nxt = (yn, mn, rn)
     check(lib.dinox_block_forward(C.byref(a), _stream()), "dinox_block_forward")
     if train:
@@ -1080,7 +1084,7 @@ class BlockFn(torch.autograd.Function):
             H = w1.shape[0]
             pre = torch.empty((M, H), dtype=dt, device=x0.device) if train else None
             act = gemm(xn2, weight_operand(w1, dt), bias=b1, gelu=True, aux=pre, auxgrad=True, out_dtype=dt)   # pre := gelu'(fc1 out)
-            if next_ln is not None and rowln_ok(M, D, H, dt):
+            if next_ln is not None and rowln_ok(M, D, H, dt, next_ln[3] or dt):
                 x2, yn, mn, rn = linear_residual_ln(act, weight_operand(w2, dt), b2, x1, next_ln[0], next_ln[1], next_ln[2], next_ln[3] or dt)
                 nxt = (yn.view(V, N, D), mn, rn)
             else:

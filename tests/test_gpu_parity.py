@@ -1208,12 +1208,17 @@ def test_gemm_nt_areg(dx, M, N, K, monkeypatch):
 @pytest.mark.parametrize("M,K,res,bias", [(1000, 384, True, True), (128 * 5 + 17, 1536, True, True), (77, 384, True, False), (128 * 3 + 70, 384, False, True),
                                           (4096, 1152, True, True), (128 * 700 + 9, 384, True, True), (300, 608, True, True)])
 @pytest.mark.parametrize("ydt", [torch.bfloat16, torch.float32])
-def test_linear_residual_ln(dx, M, K, res, bias, ydt):
+@pytest.mark.parametrize("pp", ["0", "1"])
+def test_linear_residual_ln(dx, M, K, res, bias, ydt, pp, monkeypatch):
     """dinox_linear_residual_ln (csrc/gemm_bf16_rowln.hip: x = residual + a W^T + bias and y = LayerNorm(x) with the row statistics in
     one launch, width 384) against fp64 on the same bf16 operands: x to fp32 accumulation accuracy, mean / rstd / y to LayerNorm
     accuracy; ragged M (a last tile whose second row-wave is entirely past M), no residual, no bias, a row offset that makes
-    E[x^2] - mean^2 cancel (|mean| >> std), both output dtypes; and bit-repeatable."""
+    E[x^2] - mean^2 cancel (|mean| >> std), both output dtypes; and bit-repeatable.  pp = DINOX_ROWLN_PP: 0 = the 128 x 384 kernel,
+    1 = the full-row 208 x 384 kernel with the LayerNorm epilogue (csrc/gemm_bf16_pp384.hip: bf16 y; fp32 y stays on the former)."""
     ops, _ = dx
+    monkeypatch.setenv("DINOX_ROWLN_PP", pp)
+    if pp == "1" and ydt != torch.bfloat16:
+        pytest.skip("fp32 y: one kernel only")
     N = 384
     g = torch.Generator().manual_seed(M + K)
     A, W = (torch.randn(M, K, generator=g) * 0.5).bfloat16(), (torch.randn(N, K, generator=g) * (3.0 / math.sqrt(K))).bfloat16()

@@ -123,7 +123,7 @@ __device__ __forceinline__ void store_block(bf16_t* __restrict__ dst, int64_t ro
   for (int it = 0; it < 4; ++it) {
     const int r = (lane >> 3) + 8 * it, c = lane & 7;
     const uint4 v = *reinterpret_cast<const uint4*>(scratch + r * ST_ROWB + c * 16);
-    if (row0 + r < n_valid) *reinterpret_cast<uint4*>(dst + (int64_t)(row0 + r) * row_stride + c * 8) = v;
+    if (row0 + r < n_valid) store_stream(reinterpret_cast<uint4*>(dst + (int64_t)(row0 + r) * row_stride + c * 8), v);
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();

@@ -54,6 +54,23 @@ struct elem<DINOX_BF16> {
   static __device__ __forceinline__ void st(void* p, int64_t i, float v) { ((bf16_t*)p)[i] = f32_to_bf16(v); }
 };
 
+// ---------------------------------------------------------------- device: streaming stores
+// Big outputs that the NEXT kernel reads (or nobody reads soon) leave by non-temporal stores: they do not push the operand slices of the
+// tiles still running out of L2, and the consumer finds them in the memory-side cache (measured on the LayerNorm epilogue of
+// gemm_bf16_pp384.hip: the kernel reading y next 272 -> 263 us).  HIP's uint4 / float4 are structs: the builtin wants native vectors.
+typedef unsigned dx_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned dx_u32x2 __attribute__((ext_vector_type(2)));
+template <typename T>
+__device__ __forceinline__ void store_stream(T* dst, const T& v) {
+#ifdef DINOX_PLAIN_OUT_STORES
+  *dst = v;
+#else
+  static_assert(sizeof(T) == 16 || sizeof(T) == 8, "store_stream: 8- or 16-byte values");
+  if constexpr (sizeof(T) == 16) __builtin_nontemporal_store(__builtin_bit_cast(dx_u32x4, v), reinterpret_cast<dx_u32x4*>(dst));
+  else __builtin_nontemporal_store(__builtin_bit_cast(dx_u32x2, v), reinterpret_cast<dx_u32x2*>(dst));
+#endif
+}
+
 // ---------------------------------------------------------------- device: math
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_erf_grad(float x) {

@@ -58,14 +58,14 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const float* __restr
         o.z = (v[j].z - mu) * rs * ww.z + bb.z;
         o.w = (v[j].w - mu) * rs * ww.w + bb.w;
         if (OUT_DT == DINOX_F32) {
-          reinterpret_cast<float4*>((float*)y + r * dim)[c] = o;
+          store_stream(reinterpret_cast<float4*>((float*)y + r * dim) + c, o);
         } else {
           ushort4 p;
           p.x = f32_to_bf16(o.x);
           p.y = f32_to_bf16(o.y);
           p.z = f32_to_bf16(o.z);
           p.w = f32_to_bf16(o.w);
-          reinterpret_cast<ushort4*>((bf16_t*)y + r * dim)[c] = p;
+          store_stream(reinterpret_cast<ushort4*>((bf16_t*)y + r * dim) + c, p);
         }
       }
     }
@@ -118,14 +118,14 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_384(const float* __restrict
       o.z = (v[j].z - mu) * rs * ww[j].z + bb[j].z;
       o.w = (v[j].w - mu) * rs * ww[j].w + bb[j].w;
       if (OUT_DT == DINOX_F32) {
-        reinterpret_cast<float4*>((float*)y + r * DIM)[sl + 32 * j] = o;
+        store_stream(reinterpret_cast<float4*>((float*)y + r * DIM) + (sl + 32 * j), o);
       } else {
         ushort4 p;
         p.x = f32_to_bf16(o.x);
         p.y = f32_to_bf16(o.y);
         p.z = f32_to_bf16(o.z);
         p.w = f32_to_bf16(o.w);
-        reinterpret_cast<ushort4*>((bf16_t*)y + r * DIM)[sl + 32 * j] = p;
+        store_stream(reinterpret_cast<ushort4*>((bf16_t*)y + r * DIM) + (sl + 32 * j), p);
       }
     }
   };
@@ -237,11 +237,11 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const void* __restri
         o.w = rs * (g[j].w - m1 - xh[j].w * m2);
         float4* dst = reinterpret_cast<float4*>(dx + r * dim) + c;
         o.x += add[j].x; o.y += add[j].y; o.z += add[j].z; o.w += add[j].w;
-        *dst = o;
+        store_stream(dst, o);
         if (dx_lowp) {
           ushort4 p;
           p.x = f32_to_bf16(o.x); p.y = f32_to_bf16(o.y); p.z = f32_to_bf16(o.z); p.w = f32_to_bf16(o.w);
-          reinterpret_cast<ushort4*>((bf16_t*)dx_lowp + r * dim)[c] = p;
+          store_stream(reinterpret_cast<ushort4*>((bf16_t*)dx_lowp + r * dim) + c, p);
         }
       }
     }
@@ -324,11 +324,11 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_384(const void* __restrict_
       o.y = rs * (g[j].y - m1 - xh[j].y * m2) + a[j].y;
       o.z = rs * (g[j].z - m1 - xh[j].z * m2) + a[j].z;
       o.w = rs * (g[j].w - m1 - xh[j].w * m2) + a[j].w;
-      reinterpret_cast<float4*>(dx + r * DIM)[c] = o;
+      store_stream(reinterpret_cast<float4*>(dx + r * DIM) + c, o);
       if (dx_lowp) {
         ushort4 p;
         p.x = f32_to_bf16(o.x); p.y = f32_to_bf16(o.y); p.z = f32_to_bf16(o.z); p.w = f32_to_bf16(o.w);
-        reinterpret_cast<ushort4*>((bf16_t*)dx_lowp + r * DIM)[c] = p;
+        store_stream(reinterpret_cast<ushort4*>((bf16_t*)dx_lowp + r * DIM) + c, p);
       }
     }
   };

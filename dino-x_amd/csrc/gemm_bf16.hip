@@ -585,8 +585,8 @@ static const char* nt_pp_choice(const GemmParams& p) {
   if (mode >= 1 || !pick) return pick;
   // Measured policy (tools/pp_check.py, MI355X, old = gemm_bf16_nt_areg / _glds; M = 102 912 / 51 456 / 25 728 tokens):
   //   256-wide: qkv 140 -> 104-112 us, plain K 384 N 1536 164 -> 125-131, GELU' product 186 -> 172-176 (x0.9 at every M); ViT-L qkv 425 -> 291,
-  //             fc1 651 -> 480, fc2 525 -> 452 us.  The GELU epilogue at K = 384 is the exception: it is bound by its ~50 VALU cycles per
-  //             element either way (fc1 206 vs 203-214 us), so it stays on the register-prefetch kernel until K >= 768;
+  //             fc1 651 -> 480, fc2 525 -> 452 us.  The GELU epilogue at K = 384 is bound by its ~50 VALU cycles per element either way
+  //             (fc1 206 vs 203-214 us in isolation; see below for the step);
   //   128-wide: dX K 1152 123 -> 92-96, dX K 1536 160 -> 138, fc2 196 -> 176 at every M; the K = 384 products only on a full chip
   //             (dX of proj 55 -> 45 us at M = 102 912, 28 vs 30 at 51 456) and not with the fp32 residual (proj: 83 vs 93 us).
   // Small problems (less than one round of tiles) keep the 128 x 128 kernels, whose tiles are four times as many.
@@ -595,7 +595,13 @@ static const char* nt_pp_choice(const GemmParams& p) {
     if (p.K >= 768) return units >= 192 ? pick : nullptr;
     return (units >= 1024 && !(p.epilogue & DINOX_EPI_RESIDUAL)) ? pick : nullptr;
   }
-  if ((p.epilogue & DINOX_EPI_GELU) && p.K < 768) return nullptr;
+  // (Until the last day of round 3 the GELU epilogue at K < 768 stayed on the register-prefetch kernel -- a tie in the micro-benchmark, where
+  //  the token operand sits in the memory-side cache from the previous iteration.  In the step it does not: behind the LayerNorm-fused
+  //  proj the 128 x 128 kernel takes 230 us; on the 256 x 256 tiles the step is 0.25 ms shorter.  DINOX_FC1_AREG=1 restores the old choice.)
+  if ((p.epilogue & DINOX_EPI_GELU) && p.K < 768) {
+    const char* ea = getenv("DINOX_FC1_AREG");
+    if ((ea && atoi(ea) != 0) || units < 1024) return nullptr;   // (bs 64, 606 tiles: 12.46 ms per step on the 128 x 128 kernel, 12.50 here)
+  }
   return units >= 192 ? pick : nullptr;
 }
 

@@ -123,7 +123,8 @@ def test_gemm_dispatch_by_shape(monkeypatch):
     monkeypatch.delenv("DINOX_NT_PP", raising=False)
     monkeypatch.delenv("DINOX_NT_AREG_MAXK", raising=False)
     assert name(T, 1152, 384, epi=EPI_BIAS) == "gemm_bf16_nt_pp"                                                          # qkv: 256 x 256 tiles
-    assert name(T, 1536, 384, epi=EPI_BIAS | EPI_GELU | EPI_AUXGRAD, aux=0x60000) == "gemm_bf16_nt_areg"                  # fc1: VALU-bound either way
+    assert name(T, 1536, 384, epi=EPI_BIAS | EPI_GELU | EPI_AUXGRAD, aux=0x60000) == "gemm_bf16_nt_pp"                    # fc1: 256 x 256 tiles on a full chip ...
+    assert name(T // 4, 1536, 384, epi=EPI_BIAS | EPI_GELU | EPI_AUXGRAD, aux=0x60000) == "gemm_bf16_nt_areg"             # ... the 128 x 128 kernel at bs 64
     assert name(T, 1536, 384, epi=EPI_DGELU | EPI_AUXGRAD, aux=0x60000) == "gemm_bf16_nt_pp"                              # GELU' product
     assert name(T, 384, 1536, epi=EPI_BIAS | EPI_RESIDUAL, out=F32, res=0x50000) == "gemm_bf16_nt_pp128"                  # fc2: 256 x 128 tiles
     assert name(T, 384, 1152) == "gemm_bf16_nt_pp384" and name(T, 384, 1536) == "gemm_bf16_nt_pp384"                      # dX of qkv / fc1: full-row 208 x 384 tiles

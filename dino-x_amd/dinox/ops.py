@@ -632,7 +632,14 @@ def attention_fwd(qkv: Tensor, heads: int):
 
 # "1": no-grad blocks (teacher, encode()) run qkv projection + attention as one launch.  Off by default: measured no faster than the two
 # launches at ViT-S (219-227 us against 208-222) and slower at ViT-L (500 against 408 us); csrc/attention_bf16.hip, DESIGN.md section 4
-_QKV_FUSED = os.environ.get("DINOX_QKV_FUSED", "0") == "1"
+_QKV_FUSED = {"1": True, "0": False}.get(os.environ.get("DINOX_QKV_FUSED", ""))      # None: by width (below)
+
+
+def _qkv_fused(D: int) -> bool:
+    """No-grad blocks (the teacher of a step, encode()) run qkv projection + attention as ONE launch?  In isolation a tie at ViT-S and slower
+    at ViT-L; in the step, where the teacher's qkv tensor is 237 MB written and read back between two kernels that
+    each start cold, 0.2 ms per step faster at width 384 (35.01 -> 34.80 ms, interleaved on one box).  Unset: widths up to 512."""
+    return _QKV_FUSED if _QKV_FUSED is not None else D <= 512
 
 
 def qkv_attention_ok(B: int, N: int, heads: int, D: int, C: int) -> bool:
@@ -922,7 +929,7 @@ def _block_forward_native(ctx, x0, n1w, n1b, wqkv, bqkv, wproj, bproj, n2w, n2b,
         xn1, mean1, rstd1 = bf(V, N, D), f32(M), f32(M)
     else:
         xn1, mean1, rstd1 = pre_ln
-    if not train and _QKV_FUSED and qkv_attention_ok(V, N, heads, D, D):      # no backward: projection + attention in one launch, no qkv tensor
+    if not train and _qkv_fused(D) and qkv_attention_ok(V, N, heads, D, D):      # no backward: projection + attention in one launch, no qkv tensor
         qkv, o, lse = None, bf(V, N, D), None
     else:
         qkv, o, lse = bf(M, 3 * D), bf(V, N, D), f32(V, heads, N)
@@ -1067,7 +1074,7 @@ class BlockFn(torch.autograd.Function):
             xn1, mean1, rstd1 = layernorm_fwd(x0, n1w, n1b, dt, eps)
         else:
             xn1, mean1, rstd1 = pre_ln
-        if not train and dt == torch.bfloat16 and _QKV_FUSED and qkv_attention_ok(V, N, heads, D, D):
+        if not train and dt == torch.bfloat16 and _qkv_fused(D) and qkv_attention_ok(V, N, heads, D, D):
             o, qkv, lse = qkv_attention(xn1.view(V, N, D), weight_operand(wqkv, dt), bqkv, heads)      # one launch, no qkv tensor
         else:
             qkv = gemm(xn1.view(M, D), weight_operand(wqkv, dt), bias=bqkv, out_dtype=dt)

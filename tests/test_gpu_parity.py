@@ -1835,7 +1835,8 @@ def test_gemm_tn_big_anti_phase_loop_equals_in_step_loop(dx, K, M, N, monkeypatc
 
 def test_training_steps_are_bit_reproducible(dx):
     """Two runs of three bf16 optimiser steps from the same state end in bit-identical student, teacher, Adam moments and centre:
-    no kernel of the step leaves the order of a floating-point sum to the scheduler (round 1: the split-K atomics of the dW products did)."""
+    no kernel of the step leaves the order of a floating-point sum to the scheduler (round 1: the split-K atomics of the dW products did);
+    the same again with DINOX_SIDE_STREAM / DINOX_DW_STREAM (concurrent launch chains)."""
     ops, arch = dx
     from dinox.engine import StepHyperParams, TrainEngine
     kw = dict(img_size=64, patch=16, dim=384, depth=2, heads=6, num_registers=4, scale_aware=True)
@@ -1862,6 +1863,20 @@ def test_training_steps_are_bit_reproducible(dx):
     assert la == lb
     for name, x, y in zip(("student", "teacher", "adam_m", "adam_v", "centre", "last gradient"), a, b):
         assert torch.equal(x, y), f"{name}: {int((x != y).sum())} of {x.numel()} elements differ between two identical runs"
+    # ... and with the opt-in second streams (the teacher's forward beside the student's, the weight-gradient products beside backward):
+    # another order of launches in time, the same sums
+    import os
+    was = ops.dw_stream.enabled
+    os.environ["DINOX_SIDE_STREAM"] = "1"
+    ops.dw_stream.enabled = True
+    try:
+        c, lc = run()
+    finally:
+        os.environ.pop("DINOX_SIDE_STREAM", None)
+        ops.dw_stream.enabled = was
+    assert lc == la
+    for name, x, y in zip(("student", "teacher", "adam_m", "adam_v", "centre", "last gradient"), a, c):
+        assert torch.equal(x, y), f"{name}: {int((x != y).sum())} of {x.numel()} elements differ with the side streams on"
 
 
 @pytest.mark.parametrize("amp", [False, True])

@@ -151,13 +151,18 @@ extern "C" int dinox_block_backward(const dinox_block_bwd_args* a, void* stream)
     BLK_TRY(dinox_gemm(&g, stream));
   }
   BLK_TRY(weight_grad(g_op, a->act, a->dw2, a->db2, M, D, H, a->tn_ws, a->tn_ws_bytes, stream));
-  {
+  const bool fuse_ln = (a->reserved & 1) != 0;                    // dX product + LayerNorm backward in one launch (dinox_linear_ln_bwd)
+  if (!fuse_ln) {
     dinox_gemm_args g = gemm_args(a->dpre, a->w1_t, a->dxn2, M, D, H, DINOX_BF16);
     BLK_TRY(dinox_gemm(&g, stream));
   }
   BLK_TRY(weight_grad(a->dpre, a->xn2, a->dw1, a->db1, M, H, D, a->tn_ws, a->tn_ws_bytes, stream));
   // g1 = g + LN2'(dxn2)   (+ its bf16 copy)
-  BLK_TRY(dinox_layernorm_bwd(a->dxn2, a->x1, a->n2w, a->mean2, a->rstd2, a->g1, a->g, a->g1_lowp, a->dn2w, a->dn2b, a->ln_ws, M, D, DINOX_BF16, 1, stream));
+  if (fuse_ln)
+    BLK_TRY(dinox_linear_ln_bwd(a->dpre, a->w1_t, a->x1, a->n2w, a->mean2, a->rstd2, a->g1, a->g, a->g1_lowp, a->dn2w, a->dn2b, a->ln_ws, M, (int)D,
+                                (int)H, 1, stream));
+  else
+    BLK_TRY(dinox_layernorm_bwd(a->dxn2, a->x1, a->n2w, a->mean2, a->rstd2, a->g1, a->g, a->g1_lowp, a->dn2w, a->dn2b, a->ln_ws, M, D, DINOX_BF16, 1, stream));
   // ---- attention: x1 = x0 + proj(attn(qkv(xn1)))
   {
     dinox_gemm_args g = gemm_args(a->g1_lowp, a->wproj_t, a->d_o, M, D, D, DINOX_BF16);
@@ -165,12 +170,16 @@ extern "C" int dinox_block_backward(const dinox_block_bwd_args* a, void* stream)
   }
   BLK_TRY(weight_grad(a->g1_lowp, a->o, a->dwproj, a->dbproj, M, D, D, a->tn_ws, a->tn_ws_bytes, stream));
   BLK_TRY(dinox_attention_bwd(a->d_o, a->qkv, a->o, a->lse, a->dqkv, a->attn_ws, (int)a->V, (int)a->N, a->heads, D / a->heads, DINOX_BF16, stream));
-  {
+  if (!fuse_ln) {
     dinox_gemm_args g = gemm_args(a->dqkv, a->wqkv_t, a->dxn1, M, D, 3 * (int64_t)D, DINOX_BF16);
     BLK_TRY(dinox_gemm(&g, stream));
   }
   BLK_TRY(weight_grad(a->dqkv, a->xn1, a->dwqkv, a->dbqkv, M, 3 * (int64_t)D, D, a->tn_ws, a->tn_ws_bytes, stream));
   // g0 = g1 + LN1'(dxn1), in place on g1   (+ its bf16 copy)
-  BLK_TRY(dinox_layernorm_bwd(a->dxn1, a->x0, a->n1w, a->mean1, a->rstd1, a->g1, a->g1, a->g0_lowp, a->dn1w, a->dn1b, a->ln_ws, M, D, DINOX_BF16, 1, stream));
+  if (fuse_ln)
+    BLK_TRY(dinox_linear_ln_bwd(a->dqkv, a->wqkv_t, a->x0, a->n1w, a->mean1, a->rstd1, a->g1, a->g1, a->g0_lowp, a->dn1w, a->dn1b, a->ln_ws, M, (int)D,
+                                3 * (int)D, 1, stream));
+  else
+    BLK_TRY(dinox_layernorm_bwd(a->dxn1, a->x0, a->n1w, a->mean1, a->rstd1, a->g1, a->g1, a->g0_lowp, a->dn1w, a->dn1b, a->ln_ws, M, D, DINOX_BF16, 1, stream));
   return 0;
 }

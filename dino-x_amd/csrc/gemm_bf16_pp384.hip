@@ -56,7 +56,11 @@ struct PpLnExtra {
   float eps;
 };
 
-template <int OUT_DT, bool RES, bool LN>
+// LayerNorm BACKWARD behind the product (the input-gradient product in front of a LayerNorm, then dinox_layernorm_bwd's contract):
+// dy = a W^T (rounded to bf16, as the two launches hand it over), dx = LN'(dy; x, mean, rstd, gamma) + dx_add in fp32 (+ its bf16 copy),
+// per-workgroup partial sums of d gamma / d beta in ws[tile][2][384] (ln_bwd_reduce adds them up).  Rides in PpLnExtra's slots:
+//   gamma = gamma, beta = x, y = dx_lowp, mean = mean, rstd = rstd; GemmParams: C = dx, residual = dx_add, aux = ws.
+template <int OUT_DT, bool RES, bool LN, bool LNB = false>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pp384(GemmParams p, PpLnExtra ln) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -175,7 +179,108 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pp384(GemmParams p, PpLnE
 #pragma unroll
   for (int j = 0; j < 3; ++j) bias[j] = hb ? *reinterpret_cast<const float4*>(p.bias + wv * 48 + j * 16 + fq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
   const int rows = (int)(p.M - m0 < PR_BM ? p.M - m0 : PR_BM);
-  if constexpr (OUT_DT == DINOX_BF16) {
+  if constexpr (LNB) {
+    // dy as bf16 in LDS (the whole tile, [208 rows][784 B]); behind the barrier half a wave owns a row (lane hl: columns 4 hl .. + 3 of each
+    // 128-column third -- the column map of ln_bwd_384, whose arithmetic this repeats operation for operation: dx equals the two launches' to the last bit), 13 rows per half-wave, x and dx_add requested three rows ahead; the column sums of dy x_hat and dy meet through LDS.
+    char* const orow = smem + fr * PR_OROW + (wv * 48 + fq * 4) * 2;
+#pragma unroll
+    for (int i = 0; i < PR_RB; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const pp_f32x4 v = acc[i][j];
+        uint2 pk;
+        pk.x = pp_pack2(v[0] * alpha, v[1] * alpha);
+        pk.y = pp_pack2(v[2] * alpha, v[3] * alpha);
+        *reinterpret_cast<uint2*>(orow + i * 16 * PR_OROW + j * 32) = pk;
+      }
+    PR_SYNC
+    const int hl = lane & 31, hh = lane >> 5;
+    const float* const xg = ln.beta;                            // (x rides in the beta slot)
+    const float* const gadd = p.residual;
+    float4 aw[3], ab[3], wreg[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      aw[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      ab[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      wreg[j] = reinterpret_cast<const float4*>(ln.gamma)[hl + 32 * j];
+    }
+    constexpr int NQ = PR_BM / 16;                              // 13 rows per half-wave: row = 2 wv + hh + 16 q
+    constexpr int DEPTH = 3;
+    float4 xr[DEPTH][3], ar[DEPTH][3];
+    auto fetch = [&](int q, int slot) {
+      int row = 2 * wv + hh + 16 * q;
+      row = row < rows ? row : rows - 1;                        // (valid address; the row's results are dropped)
+      const int64_t r = m0 + row;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        xr[slot][j] = reinterpret_cast<const float4*>(xg + r * PR_BN)[hl + 32 * j];
+        ar[slot][j] = gadd ? reinterpret_cast<const float4*>(gadd + r * PR_BN)[hl + 32 * j] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    };
+#pragma unroll
+    for (int q = 0; q < DEPTH - 1; ++q) fetch(q, q);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      if (q + DEPTH - 1 < NQ) fetch(q + DEPTH - 1, (q + DEPTH - 1) % DEPTH);
+      const int row = 2 * wv + hh + 16 * q;
+      if (row < rows) {
+        const int64_t r = m0 + row;
+        const float mu = ln.mean[r], rs = ln.rstd[r];
+        const float4 (&xv)[3] = xr[q % DEPTH];
+        const float4 (&a)[3] = ar[q % DEPTH];
+        float4 d[3], xh[3], g[3];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const uint2 pk = *reinterpret_cast<const uint2*>(smem + row * PR_OROW + (hl + 32 * j) * 8);
+          d[j] = make_float4(__uint_as_float(pk.x << 16), __uint_as_float(pk.x & 0xffff0000u), __uint_as_float(pk.y << 16), __uint_as_float(pk.y & 0xffff0000u));
+          xh[j] = make_float4((xv[j].x - mu) * rs, (xv[j].y - mu) * rs, (xv[j].z - mu) * rs, (xv[j].w - mu) * rs);
+          g[j] = make_float4(d[j].x * wreg[j].x, d[j].y * wreg[j].y, d[j].z * wreg[j].z, d[j].w * wreg[j].w);
+          aw[j].x += d[j].x * xh[j].x; aw[j].y += d[j].y * xh[j].y; aw[j].z += d[j].z * xh[j].z; aw[j].w += d[j].w * xh[j].w;
+          ab[j].x += d[j].x; ab[j].y += d[j].y; ab[j].z += d[j].z; ab[j].w += d[j].w;
+          s1 += (g[j].x + g[j].y) + (g[j].z + g[j].w);
+          s2 += (g[j].x * xh[j].x + g[j].y * xh[j].y) + (g[j].z * xh[j].z + g[j].w * xh[j].w);
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+          s1 += __shfl_xor(s1, o, 64);
+          s2 += __shfl_xor(s2, o, 64);
+        }
+        const float m1 = s1 * (1.0f / PR_BN), m2 = s2 * (1.0f / PR_BN);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          float4 o;
+          o.x = rs * (g[j].x - m1 - xh[j].x * m2) + a[j].x;
+          o.y = rs * (g[j].y - m1 - xh[j].y * m2) + a[j].y;
+          o.z = rs * (g[j].z - m1 - xh[j].z * m2) + a[j].z;
+          o.w = rs * (g[j].w - m1 - xh[j].w * m2) + a[j].w;
+          store_stream(reinterpret_cast<float4*>((float*)p.C + r * PR_BN) + (hl + 32 * j), o);
+          if (ln.y) {
+            ushort4 pq;
+            pq.x = f32_to_bf16(o.x); pq.y = f32_to_bf16(o.y); pq.z = f32_to_bf16(o.z); pq.w = f32_to_bf16(o.w);
+            store_stream(reinterpret_cast<ushort4*>((bf16_t*)ln.y + r * PR_BN) + (hl + 32 * j), pq);
+          }
+        }
+      }
+    }
+    PR_SYNC                                                     // the image is dead: the sixteen half-waves' column sums meet in its place
+    {
+      float* const cs = reinterpret_cast<float*>(smem) + (size_t)(2 * wv + hh) * 2 * PR_BN;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        reinterpret_cast<float4*>(cs)[hl + 32 * j] = aw[j];
+        reinterpret_cast<float4*>(cs + PR_BN)[hl + 32 * j] = ab[j];
+      }
+    }
+    PR_SYNC
+    float* const wsrow = (float*)p.aux + (size_t)blockIdx.x * 2 * PR_BN;
+    for (int c = (int)threadIdx.x; c < 2 * PR_BN; c += 512) {
+      float v = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) v += reinterpret_cast<const float*>(smem)[(size_t)k * 2 * PR_BN + c];
+      wsrow[c] = v;
+    }
+  } else if constexpr (OUT_DT == DINOX_BF16) {
     // the WHOLE tile as bf16 in LDS ([208 rows][784 B]), one barrier, then 16-byte pieces of whole rows out
     char* const orow = smem + fr * PR_OROW + (wv * 48 + fq * 4) * 2;
 #pragma unroll
@@ -382,6 +487,29 @@ int launch_gemm_bf16_nt_pp384_ln(const void* a, const void* w, const float* bias
   if (int rc = reserve_lds(reinterpret_cast<const void*>(kern), PR_LDS, "gemm_bf16_nt_pp384")) return rc;
   hipLaunchKernelGGL(kern, dim3((unsigned)units), dim3(512), PR_LDS, st, p, ln);
   return check_launch("gemm_bf16_nt_pp384(ln)");
+}
+
+// The product + LayerNorm-backward form (called by dinox_linear_ln_bwd, layernorm.hip).  ws: tiles x 2 x 384 floats.
+int pp384_lnbwd_tiles(int64_t M) { return (int)ceil_div(M, (int64_t)PR_BM); }
+
+int launch_gemm_bf16_nt_pp384_lnbwd(const void* a, const void* w, const float* x, const float* gamma, const float* mean, const float* rstd,
+                                    float* dx, const float* dx_add, void* dx_lowp, float* ws, int64_t M, int K, hipStream_t st) {
+  GemmParams p{};
+  p.A = a; p.B = w; p.C = dx;
+  p.M = M; p.N = PR_BN; p.K = K;
+  p.lda = K; p.ldb = K; p.ldc = PR_BN;
+  p.batch = 1;
+  p.in_dtype = DINOX_BF16; p.out_dtype = DINOX_BF16;
+  p.alpha = 1.0f;
+  p.residual = dx_add; p.ldr = PR_BN;
+  p.aux = ws;
+  const PpLnExtra ln{gamma, x, dx_lowp, const_cast<float*>(mean), const_cast<float*>(rstd), 0.f};
+  const int64_t units = ceil_div(M, (int64_t)PR_BM);
+  if (units > 0x3fffffff) return DINOX_EUNSUPPORTED;
+  auto kern = gemm_bf16_nt_pp384<DINOX_BF16, false, false, true>;
+  if (int rc = reserve_lds(reinterpret_cast<const void*>(kern), PR_LDS, "gemm_bf16_nt_pp384")) return rc;
+  hipLaunchKernelGGL(kern, dim3((unsigned)units), dim3(512), PR_LDS, st, p, ln);
+  return check_launch("gemm_bf16_nt_pp384(ln_bwd)");
 }
 
 }  // namespace dinox

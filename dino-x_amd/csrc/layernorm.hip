@@ -426,6 +426,12 @@ static int ln_parts(int64_t rows) {
   return (int)(p < LN_MAX_PARTS ? p : LN_MAX_PARTS);
 }
 
+// gemm_bf16_pp384.hip: the input-gradient product into width 384 with LayerNorm backward as its epilogue
+int pp384_lnbwd_tiles(int64_t M);
+bool gemm_bf16_nt_pp384_ln_ok(int64_t M, int K);
+int launch_gemm_bf16_nt_pp384_lnbwd(const void* a, const void* w, const float* x, const float* gamma, const float* mean, const float* rstd,
+                                    float* dx, const float* dx_add, void* dx_lowp, float* ws, int64_t M, int K, hipStream_t st);
+
 }  // namespace dinox
 
 using namespace dinox;
@@ -518,4 +524,25 @@ extern "C" int dinox_layernorm_bwd(const void* dy, const float* x, const float* 
   if (rc) return rc;
   hipLaunchKernelGGL(ln_bwd_reduce, dim3((unsigned)ceil_div(2 * dim, 4)), dim3(256), 0, st, wsf, dw, db, parts, dim, accumulate ? 1 : 0);
   return check_launch("layernorm_bwd_reduce");
+}
+
+// dX product + LayerNorm backward in one launch (width 384, bf16 operands):  dy = a w^T rounded to bf16 (what the two launches hand
+// over), dx = (dx_add ? dx_add : 0) + LN'(dy) -- equal to dinox_gemm + dinox_layernorm_bwd to the last bit --, dgamma / dbeta through the same
+// workspace and reduction (ws: dinox_layernorm_bwd_ws_bytes(M, 384) bytes).  dx may alias dx_add.
+extern "C" int dinox_linear_ln_bwd_ok(int64_t M, int N, int K) {
+  return (N == 384 && gemm_bf16_nt_pp384_ln_ok(M, K) && pp384_lnbwd_tiles(M) <= ln_parts(M)) ? 1 : 0;
+}
+
+extern "C" int dinox_linear_ln_bwd(const void* a, const void* w, const float* x, const float* gamma, const float* mean, const float* rstd,
+                                   float* dx, const float* dx_add, void* dx_lowp, float* dgamma, float* dbeta, void* ws, int64_t M, int N,
+                                   int K, int accumulate, void* stream) {
+  DX_REQUIRE(a && w && x && gamma && mean && rstd && dx && dgamma && dbeta && ws, DINOX_EINVAL, "linear_ln_bwd: null pointer");
+  DX_REQUIRE(dinox_linear_ln_bwd_ok(M, N, K), DINOX_EUNSUPPORTED, "linear_ln_bwd: M=%lld N=%d K=%d", (long long)M, N, K);
+  DX_REQUIRE((((uintptr_t)a | (uintptr_t)w | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)dx_add | (uintptr_t)dx_lowp | (uintptr_t)gamma) & 15) == 0,
+             DINOX_EALIGN, "linear_ln_bwd: operands must be 16-byte aligned");
+  hipStream_t st = as_stream(stream);
+  if (int rc = launch_gemm_bf16_nt_pp384_lnbwd(a, w, x, gamma, mean, rstd, dx, dx_add, dx_lowp, (float*)ws, M, K, st)) return rc;
+  hipLaunchKernelGGL(ln_bwd_reduce, dim3((unsigned)ceil_div(2 * 384, 4)), dim3(256), 0, st, (const float*)ws, dgamma, dbeta, pp384_lnbwd_tiles(M), 384,
+                     accumulate ? 1 : 0);
+  return check_launch("linear_ln_bwd_reduce");
 }

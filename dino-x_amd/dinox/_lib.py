@@ -76,6 +76,8 @@ SIGNATURES = {
     "dinox_layernorm_fwd": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, f32, i32, vp]),
     "dinox_layernorm_bwd_ws_bytes": (i64, [i64, i32]),
     "dinox_layernorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]),
+    "dinox_linear_ln_bwd_ok": (i32, [i64, i32, i32]),
+    "dinox_linear_ln_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]),
     "dinox_attention_fwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "dinox_attention_bwd_ws_bytes": (i64, [i32, i32, i32]),
     "dinox_attention_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),

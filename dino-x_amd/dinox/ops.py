@@ -521,6 +521,46 @@ def layernorm_bwd(dy: Tensor, x: Tensor, w: Tensor, mean: Tensor, rstd: Tensor, 
     return dx, dw, db, lowp
 
 
+_LNBWD_PP = os.environ.get("DINOX_LNBWD_PP")    # "0": never fuse the dX product with the LayerNorm backward behind it; "1": wherever the kernel applies
+
+
+def linear_ln_bwd_ok(M: int, D: int, K: int, dt: torch.dtype) -> bool:
+    """Should the input-gradient product into a LayerNorm and that LayerNorm's backward run as ONE launch (csrc/gemm_bf16_pp384.hip's
+    LayerNorm-backward epilogue; bf16 mode, width 384)?  Unset: on a chip's worth of rows (M >= 8192); the results equal the two launches' to the last bit."""
+    if dt != torch.bfloat16 or _LNBWD_PP == "0" or not lib.dinox_linear_ln_bwd_ok(M, D, K):
+        return False
+    return _LNBWD_PP == "1" or M >= 8192
+
+
+def linear_ln_bwd(a: Tensor, w_t: Tensor, x: Tensor, w: Tensor, mean: Tensor, rstd: Tensor, dx: Optional[Tensor] = None,
+                  dx_add: Optional[Tensor] = None, want_lowp=False, b: Optional[Tensor] = None):
+    """dy = a w_t^T (bf16), then layernorm_bwd(dy, x, w, mean, rstd, ...) in the same launch: returns (dx, dw, db, bf16 copy of dx or None)
+    exactly as layernorm_bwd does.  a [M,K] bf16, w_t [D,K] bf16 (the W^T operand of the Linear in front of the LayerNorm)."""
+    a, x = _c(a), _c(x)
+    M, K = a.shape
+    D = x.shape[-1]
+    assert w_t.shape == (D, K) and w_t.is_contiguous() and x.numel() == M * D
+    if dx is None:
+        dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    if dx_add is not None:
+        assert dx_add.is_contiguous() and dx_add.dtype == torch.float32 and dx_add.numel() == x.numel()
+    sw, sb = (grad_sink.lookup(w), grad_sink.lookup(b)) if b is not None else (None, None)
+    sunk = sw is not None and sb is not None
+    dw = sw[1].grad if sunk else torch.empty(D, dtype=torch.float32, device=x.device)
+    db = sb[1].grad if sunk else torch.empty(D, dtype=torch.float32, device=x.device)
+    lowp = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if want_lowp else None
+    ws = torch.empty(lib.dinox_layernorm_bwd_ws_bytes(M, D), dtype=torch.uint8, device=x.device)
+    if TRACE_KERNELS is not None:
+        TRACE_KERNELS.append("gemm_bf16_nt_pp384(ln_bwd)")
+    check(lib.dinox_linear_ln_bwd(_p(a), _p(w_t), _p(x), _p(w), _p(mean), _p(rstd), _p(dx), _p(dx_add), _p(lowp), _p(dw), _p(db), _p(ws),
+                                  M, D, K, int(sunk), _stream()), "dinox_linear_ln_bwd")
+    if sunk:
+        grad_sink.ready(sw)
+        grad_sink.ready(sb)
+        return dx, None, None, lowp
+    return dx, dw, db, lowp
+
+
 _ATTN_F32_REF = bool(os.environ.get("DINOX_ATTN_F32_REF"))      # fp32 attention by the per-lane reference kernels whatever the size (A/B, tests)
 
 
@@ -1012,7 +1052,8 @@ def _block_backward_native(ctx, g: Tensor, saved):
                    attn_ws=torch.empty(lib.dinox_attention_bwd_ws_bytes(V, N, heads), dtype=torch.uint8, device=dev),
                    ln_ws=torch.empty(lib.dinox_layernorm_bwd_ws_bytes(M, D), dtype=torch.uint8, device=dev))
     wts = [weight_operand(w_, dt, transposed=True) for w_ in (wqkv, wproj, w1, w2)]
-    a = BlockBwdArgs(V=V, N=N, D=D, H=H, heads=heads, g=_p(g), g_lowp=_p(g_lp), g_lowp_buf=_p(scratch["g_lowp_buf"]),
+    fuse_ln = linear_ln_bwd_ok(M, D, H, dt) and linear_ln_bwd_ok(M, D, 3 * D, dt)      # (the same decision as the Python-sequenced backward)
+    a = BlockBwdArgs(V=V, N=N, D=D, H=H, heads=heads, reserved=int(fuse_ln), g=_p(g), g_lowp=_p(g_lp), g_lowp_buf=_p(scratch["g_lowp_buf"]),
                      x0=_p(x0), x1=_p(x1), xn1=_p(xn1), xn2=_p(xn2), qkv=_p(qkv), o=_p(o), lse=_p(lse), pre=_p(pre), act=_p(act), mean1=_p(mean1),
                      rstd1=_p(rstd1), mean2=_p(mean2), rstd2=_p(rstd2), n1w=_p(n1w), n2w=_p(n2w),
                      wqkv_t=_p(wts[0]), wproj_t=_p(wts[1]), w1_t=_p(wts[2]), w2_t=_p(wts[3]),
@@ -1135,10 +1176,15 @@ class BlockFn(torch.autograd.Function):
         dpre = gemm(g_op, b, dgelu=True, aux=pre, auxgrad=True, out_dtype=dt, **kw)
         dw2, db2 = weight_grad(g_op, act, w2, b2, b2 is not None)
         b, kw = wt(w1)
-        dxn2 = gemm(dpre, b, out_dtype=dt, **kw)
+        fuse_ln = bf and linear_ln_bwd_ok(M, D, dpre.shape[1], dt) and linear_ln_bwd_ok(M, D, 3 * D, dt)
+        if not fuse_ln:
+            dxn2 = gemm(dpre, b, out_dtype=dt, **kw)
         dw1, db1 = weight_grad(dpre, xn2.view(M, D), w1, b1, b1 is not None)
+        if fuse_ln:     # g1 = g + LN2'(dpre W1): product and LayerNorm backward in one launch
+            g1, dn2w, dn2b, g1_lp = linear_ln_bwd(dpre, b, x1, n2w, mean2, rstd2, dx_add=g.view(M, D), want_lowp=True, b=n2b)
+        else:
+            g1, dn2w, dn2b, g1_lp = layernorm_bwd(dxn2, x1, n2w, mean2, rstd2, dx_add=g.view(M, D), want_lowp=bf, b=n2b)   # g1 = g + LN2'(.)
         del dpre
-        g1, dn2w, dn2b, g1_lp = layernorm_bwd(dxn2, x1, n2w, mean2, rstd2, dx_add=g.view(M, D), want_lowp=bf, b=n2b)   # g1 = g + LN2'(.)
         g1_op = g1_lp if bf else g1
         # ---- attention: x1 = x0 + proj(attn(qkv(xn1)))
         b, kw = wt(wproj)
@@ -1146,11 +1192,15 @@ class BlockFn(torch.autograd.Function):
         dwp, dbp = weight_grad(g1_op, o.view(M, D), wproj, bproj, bproj is not None)
         dqkv = attention_bwd(do.view(V, N, D), qkv.view(V, N, 3 * D), o, lse, heads).view(M, 3 * D)
         b, kw = wt(wqkv)
-        dxn1 = gemm(dqkv, b, out_dtype=dt, **kw)
+        if not fuse_ln:
+            dxn1 = gemm(dqkv, b, out_dtype=dt, **kw)
         dwq, dbq = weight_grad(dqkv, xn1.view(M, D), wqkv, bqkv, bqkv is not None)
         if not bf:
             dw_stream.join()        # fp32 mode: the proj dW product reads g1 itself (bf16 mode: its own low-precision copy)
-        g0, dn1w, dn1b, g0_lp = layernorm_bwd(dxn1, x0, n1w, mean1, rstd1, dx=g1, dx_add=g1, want_lowp=bf, b=n1b)      # in place on our own g1
+        if fuse_ln:
+            g0, dn1w, dn1b, g0_lp = linear_ln_bwd(dqkv, b, x0, n1w, mean1, rstd1, dx=g1, dx_add=g1, want_lowp=True, b=n1b)   # in place on our own g1
+        else:
+            g0, dn1w, dn1b, g0_lp = layernorm_bwd(dxn1, x0, n1w, mean1, rstd1, dx=g1, dx_add=g1, want_lowp=bf, b=n1b)      # in place on our own g1
         g0 = g0.view(V, N, D)
         if g0_lp is not None:
             lowp_cache.put(g0, g0_lp.view(V, N, D))

@@ -146,6 +146,13 @@ int64_t dinox_layernorm_bwd_ws_bytes(int64_t rows, int dim);
 int dinox_layernorm_bwd(const void* dy, const float* x, const float* w, const float* mean, const float* rstd,
                         float* dx, const float* dx_add, void* dx_lowp, float* dw, float* db, void* ws,
                         int64_t rows, int dim, int dy_dtype, int accumulate, void* stream);
+/* The input-gradient product in front of a LayerNorm and that LayerNorm's backward as ONE launch (width N = 384, bf16 operands;
+ * backward of zoo/arch.py:95-96 with :46 / :75): dy = a w^T (a [M,K], w [384,K] = W^T of the Linear, rounded to bf16 as dinox_gemm
+ * would hand it over), then dinox_layernorm_bwd's contract on it -- dx equal to the two calls to the last bit.  ws as dinox_layernorm_bwd. */
+int dinox_linear_ln_bwd_ok(int64_t M, int N, int K);
+int dinox_linear_ln_bwd(const void* a, const void* w, const float* x, const float* gamma, const float* mean, const float* rstd,
+                        float* dx, const float* dx_add, void* dx_lowp, float* dgamma, float* dbeta, void* ws, int64_t M, int N,
+                        int K, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Multi-head self-attention core -- replaces the reshape/permute/unbind +
@@ -380,7 +387,7 @@ typedef struct dinox_block_fwd_args {
 typedef struct dinox_block_bwd_args {
   int64_t V, N;
   int32_t D, H, heads;
-  int32_t reserved;
+  int32_t reserved;                             /* flags: bit 0 = the two dX products into the LayerNorms run dinox_linear_ln_bwd */
   const float* g; const void* g_lowp; void* g_lowp_buf;
   /* saved by the forward */
   const float* x0; const float* x1; const void* xn1; const void* xn2; const void* qkv; const void* o; const float* lse;

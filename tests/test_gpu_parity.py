@@ -1247,6 +1247,52 @@ def test_linear_residual_ln(dx, M, K, res, bias, ydt, pp, monkeypatch):
     assert rel_l2(y.float(), yg.float()) < (4e-3 if ydt == torch.bfloat16 else 2e-5) and rel_l2(rstd, rg) < 1e-5
 
 
+@pytest.mark.parametrize("M,K,add", [(4096 + 17, 1536, "other"), (208 * 9 + 1, 1152, "alias"), (5000, 384, None), (90, 128, "other"), (208 * 40, 1152, "alias")])
+def test_linear_ln_bwd_equals_two_launches(dx, M, K, add, monkeypatch):
+    """dinox_linear_ln_bwd (csrc/gemm_bf16_pp384.hip's LayerNorm-backward epilogue: the input-gradient product into width 384 and the
+    LayerNorm backward behind it in one launch) against dinox_gemm + dinox_layernorm_bwd: dx equal to the last bit (dy is rounded to
+    bf16 in both and the row arithmetic is the same source, compiled twice), d gamma / d beta equal to the summation order of their row
+    sums, every launch bit-repeatable; ragged last tiles, dx aliasing dx_add (the in-place LN1 form), no dx_add; and against fp64."""
+    ops, _ = dx
+    monkeypatch.setenv("DINOX_NT_PP384", "1")     # the stand-alone product on the same K loop (as in the step: M >= 8192, K >= 768)
+    N = 384
+    g = torch.Generator().manual_seed(M + K)
+    A = (torch.randn(M, K, generator=g) * 0.5).bfloat16().to(DEV)
+    Wt = (torch.randn(N, K, generator=g) * (2.0 / math.sqrt(K))).bfloat16().to(DEV)
+    x = (torch.randn(M, N, generator=g) * 2 + 3.0 * torch.randn(M, 1, generator=g)).to(DEV)
+    gamma = (1 + 0.2 * torch.randn(N, generator=g)).to(DEV)
+    mean = x.mean(-1)
+    rstd = 1 / torch.sqrt(x.var(-1, unbiased=False) + 1e-5)
+    base = torch.randn(M, N, generator=g).to(DEV) if add else None
+
+    def run(fused):
+        dx_add = None if add is None else base.clone()
+        dx_buf = dx_add if add == "alias" else None
+        if fused:
+            return ops.linear_ln_bwd(A, Wt, x, gamma, mean, rstd, dx=dx_buf, dx_add=dx_add, want_lowp=True)
+        dy = ops.gemm(A, Wt)
+        return ops.layernorm_bwd(dy, x, gamma, mean, rstd, dx=dx_buf, dx_add=dx_add, want_lowp=True)
+
+    import dinox._lib as L_
+    assert L_.lib.dinox_linear_ln_bwd_ok(M, N, K) == 1
+    d0, w0, b0, l0 = run(False)
+    d1, w1, b1, l1 = run(True)
+    d2, w2, b2, l2 = run(True)
+    assert torch.equal(d1, d2) and torch.equal(w1, w2) and torch.equal(b1, b2) and torch.equal(l1, l2)
+    # the same dy (bf16), the same formulas -- compiled twice: one element in a hundred differs in the last bit
+    assert float((d1 - d0).abs().max()) <= 2e-6 * float(d0.abs().max()) and int((d1 != d0).sum()) < d1.numel() // 20
+    assert int((l1 != l0).sum()) < l1.numel() // 500
+    close(w1, w0.double().cpu(), 1e-5, 1e-4, "d gamma")
+    close(b1, b0.double().cpu(), 1e-5, 1e-4, "d beta")
+    # fp64 on the bf16-rounded dy
+    dy = (A.double().cpu() @ Wt.double().cpu().t()).to(torch.bfloat16).double()
+    xh = (x.double().cpu() - mean.double().cpu()[:, None]) * rstd.double().cpu()[:, None]
+    gy = dy * gamma.double().cpu()
+    ref = rstd.double().cpu()[:, None] * (gy - gy.mean(-1, keepdim=True) - xh * (gy * xh).mean(-1, keepdim=True)) + (base.double().cpu() if add else 0)
+    assert rel_l2(d1, ref) < 2e-3                 # (a bf16 rounding of dy on either side of a tie moves single elements)
+    assert rel_l2(w1, (dy * xh).sum(0)) < 2e-3 and rel_l2(b1, dy.sum(0)) < 2e-3
+
+
 def test_gemm_nt_store_policy_is_only_a_hint(dx, monkeypatch):
     """The register-prefetch kernel writes its bf16 outputs with non-temporal stores (DINOX_NT_STORES, csrc/gemm_bf16_areg.hip): a cache
     hint, so results must be bit-identical with it off, for the plain, GELU (+ side tensor) and GELU' forms."""

@@ -401,10 +401,11 @@ extern "C" int dinox_linear_residual_ln(const void* a, const void* w, const floa
   hipStream_t st = as_stream(stream);
   {
     // The full-row 208 x 384 kernel with the LayerNorm epilogue (gemm_bf16_pp384.hip) for bf16 y on a chip's worth of rows.
-    // DINOX_ROWLN_PP (read per call): 0 = never, 1 = every shape in its envelope (tests), unset = M >= 8192.
+    // DINOX_ROWLN_PP (read per call): 0 = never, 1 = every shape in its envelope (tests), unset = M >= 40000 (about a round of its 208-row
+    // tiles: at bs 64, M = 25 728 = 124 tiles, the step is 0.25 ms shorter on the 128 x 384 kernel's 201 tiles).
     const char* e = getenv("DINOX_ROWLN_PP");
     const int mode = e ? atoi(e) : -1;
-    if (y_dtype == DINOX_BF16 && mode != 0 && gemm_bf16_nt_pp384_ln_ok(M, K) && (mode > 0 || M >= 8192))
+    if (y_dtype == DINOX_BF16 && mode != 0 && gemm_bf16_nt_pp384_ln_ok(M, K) && (mode > 0 || M >= 40000))
       return launch_gemm_bf16_nt_pp384_ln(a, w, bias, residual, x_out, gamma, beta, eps, y, mean, rstd, M, K, st);
   }
 #define RL_LAUNCH(YDT, NS)                                                                                                        \

@@ -463,13 +463,13 @@ _ROWLN = os.environ.get("DINOX_ROWLN")          # "1": every width-384 product, 
 def rowln_ok(M: int, N: int, K: int, dt: torch.dtype, y_dtype: Optional[torch.dtype] = None) -> bool:
     """Should this product + the LayerNorm behind it run as ONE launch (bf16 mode, N = 384)?  Measured on MI355X at the hot-path shape
     (M = 102 912):
-      * csrc/gemm_bf16_pp384.hip's LayerNorm epilogue (bf16 y, M >= 8192: 208 x 384 full-row tiles; DINOX_ROWLN_PP=0 disables):
+      * csrc/gemm_bf16_pp384.hip's LayerNorm epilogue (bf16 y, M >= 40000 = about a round of its 208 x 384 tiles; DINOX_ROWLN_PP=0 disables):
         proj + LN 103 us against 85 + 44 us for the two launches; fc2 + LN 206 us against 177 + 44 -> both fused;
       * csrc/gemm_bf16_rowln.hip (128 x 384 tiles: fp32 y, small M): proj + LN 130 us against 85 + 44 -> fused for short reductions
         (K <= 576); fc2 + LN 256 us against 177 + 44 -> not fused unless DINOX_ROWLN=1."""
     if dt != torch.bfloat16 or _ROWLN == "0" or not lib.dinox_linear_residual_ln_ok(M, N, K):
         return False
-    full_row = _ROWLN_PP != "0" and M >= 8192 and (y_dtype or dt) == torch.bfloat16 and K >= 128
+    full_row = _ROWLN_PP != "0" and M >= 40000 and (y_dtype or dt) == torch.bfloat16 and K >= 128     # (the library's rule)
     return _ROWLN == "1" or K <= 576 or (full_row and os.environ.get("DINOX_ROWLN_FC2") != "0")
 
 

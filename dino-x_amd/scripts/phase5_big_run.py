@@ -583,6 +583,10 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--hip-graph", action="store_true",
                     help="Replay the whole optimiser step as one captured hipGraph after two eager steps (extension; single GPU, "
                          "--accumulation-steps 1): for small batches, where launching ~300 kernels per step costs more than running them")
+    ap.add_argument("--streams", choices=("auto", "on", "off"), default="auto",
+                    help="Concurrent launch chains (extension; results are bit-identical either way): the teacher's forward beside the "
+                         "student's and the weight-gradient products beside backward, each on a second HIP stream.  auto = both, the "
+                         "teacher's stream only below width 1024 (measured: ViT-S +3 .. +9 %, ViT-L -5 % with it); not under --hip-graph")
     ap.add_argument("--stack-cache", type=Path, default=None, metavar="DIR",
                     help="Keep every decoded PNG slice as raw uint16 in a memory-mapped file under DIR (keyed by the file list, sizes and "
                          "mtimes): a slice is decoded once, later epochs read it from the page cache")
@@ -780,6 +784,13 @@ def main(argv=None) -> None:
                          koleo_weight=args.koleo_weight)
     if args.hip_graph and (world > 1 or args.accumulation_steps != 1 or args.local_crops):
         raise SystemExit("--hip-graph: single GPU, --accumulation-steps 1 and no --local-crops (the captured step has one fixed batch layout)")
+    if device.type == "cuda" and not args.hip_graph and args.streams != "off":
+        # (the environment wins: DINOX_SIDE_STREAM / DINOX_DW_STREAM set by the user are left alone)
+        if "DINOX_SIDE_STREAM" not in os.environ and (args.streams == "on" or model_cfg.dim < 1024):
+            os.environ["DINOX_SIDE_STREAM"] = "1"
+        if "DINOX_DW_STREAM" not in os.environ:
+            ops.dw_stream.enabled = True
+        say(f"streams side={int(bool(os.environ.get('DINOX_SIDE_STREAM')))} dw={int(ops.dw_stream.enabled)}")
     eng = TrainEngine(student, teacher, model_cfg.out_dim, hp, amp_dtype=torch.bfloat16 if args.amp else None,
                       accumulation_steps=args.accumulation_steps, use_graph=bool(args.hip_graph))
     start_step = 0

@@ -34,7 +34,7 @@ def test_flag_surface_matches_reference(cli):
     have = {s for a in ap._actions for s in a.option_strings if s.startswith("--")} - {"--help"}
     assert set(REFERENCE_FLAGS) <= have
     assert have - set(REFERENCE_FLAGS) == {"--synthetic", "--gpu-views", "--local-crops", "--local-size", "--hip-graph", "--stack-cache",
-                                               "--stack-cache-prefill"}                                                  # the documented extensions
+                                               "--stack-cache-prefill", "--streams"}                                                  # the documented extensions
     d = vars(ap.parse_args([]))
     for k, v in REFERENCE_DEFAULTS.items():
         assert d[k] == v, k

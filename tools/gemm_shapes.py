@@ -7,7 +7,10 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "dino-x_amd")]
 import torch, bench
 from dinox import ops
 dev = torch.device("cuda:0")
-wl = bench.Workload(dev, 0, B=256)
+kw = dict(B=int(os.environ.get("B", 256)))
+if os.environ.get("MODEL"):
+    kw["model"] = os.environ["MODEL"]
+wl = bench.Workload(dev, 0, **kw)
 for _ in range(3): wl.step()
 torch.cuda.synchronize()
 t = ops.GemmTimer(every=1)
